@@ -1,0 +1,176 @@
+/*
+ * sph_amd.h — C ABI of the MI355X (gfx950) SPH compute library, libsph_amd.so.
+ *
+ * This library replaces the compute/ subsystem of grzegorz-k-karch/sph:
+ *   initParticles / updateParticles / vecNormalize   (reference compute/compute.h:4-8)
+ *   the mutable parameter globals                    (reference compute/compute.cpp:8-20)
+ *
+ * All entry points are extern "C", take plain pointers and sizes, and return an int status
+ * (SPH_OK == 0).  On failure sph_last_error() returns a thread-local message.  Nothing here
+ * runs on the CPU: every compute entry point launches hand-written HIP kernels and fails with
+ * SPH_ERR_NO_DEVICE if no gfx950 device is usable.
+ *
+ * Particle arrays handed across this boundary use the reference's layout: array-of-structures
+ * xyz, float[3*n] for positions and float[3*n] for velocities (reference main.cpp:9-10,
+ * compute/compute.cpp:104-105).  Inside the library the state is structure-of-arrays fp32 in
+ * HBM, kept in grid-sorted order between steps, with a particle-id array so that downloads
+ * come back in caller order.
+ */
+#ifndef SPH_AMD_H
+#define SPH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+  SPH_OK = 0,
+  SPH_ERR_INVALID = 1,    /* bad argument (null pointer, n > n_max, non-finite parameter ...)    */
+  SPH_ERR_NO_DEVICE = 2,  /* no usable HIP device / wrong architecture                           */
+  SPH_ERR_HIP = 3,        /* a HIP runtime call or kernel launch failed                          */
+  SPH_ERR_CAPACITY = 4,   /* particle or cell capacity of the context exceeded                   */
+  SPH_ERR_STATE = 5       /* call order violated (e.g. step before upload)                       */
+};
+
+/* ---- flags for sph_params.flags ------------------------------------------------------------ */
+enum {
+  /* Surface-tension force (reference compute.cpp:225-262).  ON by default: the reference
+   * computes it although its README lists it as unused. */
+  SPH_FLAG_SURFACE_TENSION = 1u << 0,
+  /* Neighbour contributions are summed in ascending particle-id order, which is the order in
+   * which the reference's j = 0..N-1 loops meet them (non-neighbour terms there are exactly
+   * +-0).  Results are then bit-identical to the reference.  Costs O(neighbours x candidates)
+   * per particle instead of O(candidates); meant for verification, not for throughput. */
+  SPH_FLAG_EXACT_ORDER = 1u << 1,
+  /* Keep per-particle total force density and neighbour counts of the last step for
+   * sph_download_debug (costs 16 B/particle of extra stores per step). */
+  SPH_FLAG_KEEP_DEBUG = 1u << 2
+};
+
+/*
+ * Simulation parameters.  One field per mutable global of the reference
+ * (compute/compute.cpp:8-17); defaults from sph_params_default() are the reference's values.
+ * h2/h6/h9 and the kernel coefficients are derived inside the library exactly as the reference
+ * derives them (compute.cpp:100-102 and the expressions at :45,:56,:68,:80,:92).
+ */
+typedef struct sph_params {
+  float sound_speed;   /* soundSpeed  = 1.0          compute.cpp:8  */
+  float mass;          /* m           = 0.00020543   compute.cpp:9  */
+  float rho0;          /* rho0        = 600.0        compute.cpp:10 */
+  float dyn_visc;      /* dynVisc     = 0.2          compute.cpp:11 */
+  float gravity[3];    /* a_gravity   = {0,-10,0}    compute.cpp:12 */
+  float timestep;      /* timestep    = 0.005        compute.cpp:13 */
+  float tank_size;     /* tankSize    = 0.2154       compute.cpp:14 */
+  float surf_tension;  /* surfTension = 0.0728       compute.cpp:15 */
+  float h;             /* h           = 0.01         compute.cpp:17 */
+  /* Edge of a neighbour-search cell.  0 selects h*(1+2^-12): with that pad the 27-cell
+   * stencil provably contains every pair whose fp32 distance test sqrtf(r2) <= h passes. */
+  float cell_size;
+  uint32_t flags;      /* SPH_FLAG_*  */
+  uint32_t reserved;
+} sph_params;
+
+/* Opaque simulation context: one per GPU (one per process rank in multi-GPU runs). */
+typedef struct sph_context sph_context;
+
+/* Per-kernel timings accumulated by HIP events on the context's stream. */
+typedef struct sph_timings {
+  double hash_ms;       /* cell hash + histogram                        */
+  double scan_ms;       /* prefix sum over cell counts                  */
+  double reorder_ms;    /* scatter + in-cell id ordering + state gather */
+  double density_ms;    /* density pass  (reference compute.cpp:131-150) */
+  double force_ms;      /* pressure+viscosity+gravity+tension+integrate+walls (:153-319) */
+  double other_ms;      /* pack/unpack, memsets                          */
+  uint64_t steps;       /* steps accumulated since the last reset        */
+  uint64_t particles;   /* sum over steps of particles advanced          */
+} sph_timings;
+
+/* Library identification, e.g. "sph_amd 0.1 gfx950". */
+const char* sph_version(void);
+/* Thread-local text of the last error on the calling thread ("" if none). */
+const char* sph_last_error(void);
+
+/* Fill *p with the reference's default parameters (compute.cpp:8-17), surface tension on. */
+int sph_params_default(sph_params* p);
+
+/* Number of HIP devices visible to the process; 0 without a GPU (never fails). */
+int sph_device_count(void);
+
+/*
+ * Create a context on HIP device `device` able to hold n_max particles (own + ghost).
+ * The neighbour grid is sized from params->tank_size / cell size.  Counterpart of the
+ * allocation half of initParticles (compute.cpp:97-105).
+ */
+int sph_create(const sph_params* params, int n_max, int device, sph_context** out);
+int sph_destroy(sph_context* ctx);
+
+/* Replace mutable parameters between steps (the reference's globals can be edited between
+ * updateParticles calls, e.g. a_gravity for sloshing).  h, tank_size and cell_size define the
+ * grid: changing them beyond the created grid's capacity is SPH_ERR_CAPACITY. */
+int sph_set_params(sph_context* ctx, const sph_params* params);
+int sph_get_params(const sph_context* ctx, sph_params* params);
+
+/* Host -> HBM.  pos_aos/vel_aos: float[3*n] in caller order; particle i gets id i. */
+int sph_upload(sph_context* ctx, const float* pos_aos, const float* vel_aos, int n);
+/* Same, from device pointers (HBM-resident inputs; no PCIe traffic). */
+int sph_upload_device(sph_context* ctx, const float* d_pos_aos, const float* d_vel_aos, int n);
+
+/*
+ * Advance nsteps time steps; each step is one updateParticles (compute.cpp:120-320):
+ * cell hash -> counting sort -> density -> forces -> integrate -> tank walls.
+ * Asynchronous on the context's stream; sph_download / sph_sync wait for it.
+ */
+int sph_step(sph_context* ctx, int nsteps);
+int sph_sync(sph_context* ctx);
+
+/* HBM -> host, caller order (via the id permutation).  Either pointer may be NULL. */
+int sph_download(sph_context* ctx, float* pos_aos, float* vel_aos);
+/* Same, to device pointers. */
+int sph_download_device(sph_context* ctx, float* d_pos_aos, float* d_vel_aos);
+
+/*
+ * Intermediates of the LAST step in caller order; any pointer may be NULL.
+ *   rho[n]      densities                          (compute.cpp:148)
+ *   force[3n]   total force density f_total        (compute.cpp:122, before integration)
+ *   ncount[n]   #{j : sqrtf(r2_ij) <= h}, self included
+ *   cell[n]     linear cell id (cz*ny + cy)*nx + cx of the position the step started from
+ * force and ncount need SPH_FLAG_KEEP_DEBUG.
+ */
+int sph_download_debug(sph_context* ctx, float* rho, float* force, int32_t* ncount,
+                       int32_t* cell);
+
+/* Number of particles currently held, grid dimensions (cells per axis). */
+int sph_num_particles(const sph_context* ctx);
+int sph_grid_dims(const sph_context* ctx, int dims[3]);
+
+/* Event timing: when enabled every kernel launch is bracketed by HIP events on the stream it
+ * is launched on; sph_get_timings synchronises and returns the accumulated sums. */
+int sph_enable_timing(sph_context* ctx, int enable);
+int sph_get_timings(sph_context* ctx, sph_timings* out);
+int sph_reset_timings(sph_context* ctx);
+
+/*
+ * One-call form of the reference's updateParticles(particles, velocities, numParticles)
+ * (compute.h:6): upload -> one step -> download on a process-wide default context created on
+ * first use (device 0, or $SPH_AMD_DEVICE).  `params` NULL means the reference defaults.
+ */
+int sph_update_particles(const sph_params* params, float* particles, float* velocities,
+                         int num_particles);
+
+/*
+ * Counterpart of initParticles' fill (compute.cpp:106-117): uniform random block in
+ * [0, tank/2]^3 from a 64-bit LCG seeded with `seed`, zero velocities, written to host arrays
+ * the caller owns.  (The reference seeds glibc rand() with time(0), which is not reproducible;
+ * a seed is the one deliberate difference.)
+ */
+int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos_aos,
+                          float* vel_aos, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_AMD_H */
