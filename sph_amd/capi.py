@@ -1,0 +1,200 @@
+"""ctypes binding of libsph_amd.so (the C ABI in include/sph_amd.h).
+
+The library is the product; this module only marshals numpy arrays and raw device pointers
+across the C boundary.  Loading fails loudly when the in-tree library has not been built —
+there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import (SPH_FLAG_EXACT_ORDER, SPH_FLAG_KEEP_DEBUG, SPH_FLAG_SURFACE_TENSION,  # noqa: F401
+                     SphParams, SphTimings, default_params)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsph_amd.so")
+
+# Every symbol include/sph_amd.h declares: (name, restype, argtypes)
+_P = C.POINTER(SphParams)
+_CTX = C.c_void_p
+_SIGNATURES = [
+    ("sph_version", C.c_char_p, []),
+    ("sph_last_error", C.c_char_p, []),
+    ("sph_params_default", C.c_int, [_P]),
+    ("sph_device_count", C.c_int, []),
+    ("sph_create", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_CTX)]),
+    ("sph_destroy", C.c_int, [_CTX]),
+    ("sph_set_params", C.c_int, [_CTX, _P]),
+    ("sph_get_params", C.c_int, [_CTX, _P]),
+    ("sph_upload", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_upload_device", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_step", C.c_int, [_CTX, C.c_int]),
+    ("sph_sync", C.c_int, [_CTX]),
+    ("sph_download", C.c_int, [_CTX, C.c_void_p, C.c_void_p]),
+    ("sph_download_device", C.c_int, [_CTX, C.c_void_p, C.c_void_p]),
+    ("sph_download_debug", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("sph_num_particles", C.c_int, [_CTX]),
+    ("sph_grid_dims", C.c_int, [_CTX, C.POINTER(C.c_int * 3)]),
+    ("sph_enable_timing", C.c_int, [_CTX, C.c_int]),
+    ("sph_get_timings", C.c_int, [_CTX, C.POINTER(SphTimings)]),
+    ("sph_reset_timings", C.c_int, [_CTX]),
+    ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_fill_random_block", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
+]
+
+_lib = None
+
+
+class SphError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"sph_amd error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """Load libsph_amd.so and bind every declared symbol; raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        # torch ships its own libamdhip64/libhsa-runtime64.  A process must run on ONE HIP runtime:
+        # if libsph_amd.so pulled in /opt/rocm's copy first, a later `import torch` would find no
+        # GPU.  Loading torch first makes both sides resolve to the same runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP library first (make -C sph_amd/csrc, or "
+            "__graft_entry__.build()).  sph_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return [name for name, _, _ in _SIGNATURES]
+
+
+def _check(rc):
+    if rc != 0:
+        raise SphError(rc, load().sph_last_error().decode())
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Simulation:
+    """One GPU context: mirrors the reference's initParticles / updateParticles life cycle
+    (reference compute/compute.h:4-6) with the state resident in HBM between steps."""
+
+    def __init__(self, params=None, n_max=3000, device=0):
+        self.lib = load()
+        self.params = params.copy() if params is not None else default_params()
+        self._ctx = _CTX()
+        _check(self.lib.sph_create(C.byref(self.params), int(n_max), int(device), C.byref(self._ctx)))
+        self.n_max = int(n_max)
+
+    def close(self):
+        if self._ctx:
+            self.lib.sph_destroy(self._ctx)
+            self._ctx = _CTX()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def n(self):
+        return int(self.lib.sph_num_particles(self._ctx))
+
+    def grid_dims(self):
+        d = (C.c_int * 3)()
+        _check(self.lib.sph_grid_dims(self._ctx, C.byref(d)))
+        return tuple(d)
+
+    def set_params(self, params):
+        _check(self.lib.sph_set_params(self._ctx, C.byref(params)))
+        self.params = params.copy()
+
+    def set_gravity(self, g):
+        p = self.params.copy()
+        p.gravity[0], p.gravity[1], p.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+        self.set_params(p)
+
+    def upload(self, pos, vel):
+        pos, vel = _f32(pos), _f32(vel)
+        n = pos.size // 3
+        assert vel.size == pos.size
+        _check(self.lib.sph_upload(self._ctx, pos.ctypes.data, vel.ctypes.data, n))
+
+    def upload_device(self, d_pos_ptr, d_vel_ptr, n):
+        _check(self.lib.sph_upload_device(self._ctx, C.c_void_p(d_pos_ptr), C.c_void_p(d_vel_ptr), int(n)))
+
+    def step(self, nsteps=1):
+        _check(self.lib.sph_step(self._ctx, int(nsteps)))
+
+    def sync(self):
+        _check(self.lib.sph_sync(self._ctx))
+
+    def download(self):
+        n = self.n
+        pos = np.empty((n, 3), np.float32)
+        vel = np.empty((n, 3), np.float32)
+        _check(self.lib.sph_download(self._ctx, pos.ctypes.data, vel.ctypes.data))
+        return pos, vel
+
+    def download_device(self, d_pos_ptr, d_vel_ptr):
+        _check(self.lib.sph_download_device(self._ctx, C.c_void_p(d_pos_ptr), C.c_void_p(d_vel_ptr)))
+
+    def download_debug(self, force=True, ncount=True):
+        n = self.n
+        rho = np.empty(n, np.float32)
+        f = np.empty((n, 3), np.float32) if force else None
+        nc = np.empty(n, np.int32) if ncount else None
+        cell = np.empty(n, np.int32)
+        _check(self.lib.sph_download_debug(self._ctx, rho.ctypes.data, f.ctypes.data if force else None,
+                                           nc.ctypes.data if ncount else None, cell.ctypes.data))
+        return rho, f, nc, cell
+
+    def enable_timing(self, on=True):
+        _check(self.lib.sph_enable_timing(self._ctx, 1 if on else 0))
+
+    def reset_timings(self):
+        _check(self.lib.sph_reset_timings(self._ctx))
+
+    def timings(self):
+        t = SphTimings()
+        _check(self.lib.sph_get_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in SphTimings._fields_}
+
+
+def update_particles(pos, vel, params=None):
+    """One-call updateParticles (reference compute.h:6): arrays are advanced in place."""
+    lib = load()
+    assert pos.dtype == np.float32 and vel.dtype == np.float32 and pos.flags.c_contiguous and vel.flags.c_contiguous
+    _check(lib.sph_update_particles(C.byref(params) if params is not None else None, pos.ctypes.data,
+                                    vel.ctypes.data, pos.size // 3))
+
+
+def fill_random_block(n, params=None, seed=1):
+    lib = load()
+    params = params if params is not None else default_params()
+    pos = np.empty((n, 3), np.float32)
+    vel = np.empty((n, 3), np.float32)
+    _check(lib.sph_fill_random_block(C.byref(params), seed, pos.ctypes.data, vel.ctypes.data, n))
+    return pos, vel

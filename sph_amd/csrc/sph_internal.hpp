@@ -1,0 +1,66 @@
+// Internal interface between the C ABI (sph_api.cpp) and the gfx950 kernels (sph_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sph_amd.h"
+
+namespace sph {
+
+// Everything a kernel needs, passed by value as a kernel argument.
+// The coefficients are doubles on purpose: the reference forms coefficient*polynomial in
+// double (M_PI is a double) and rounds once to float (reference compute.cpp:45,56,68,80,92).
+struct DevParams {
+  double c_poly6, c_spiky_grad, c_visc_lapl, c_poly6_grad, c_poly6_lapl;
+  float h, h2, r2_max;       // r2_max = max{x : sqrtf(x) <= h}: the reference's `r <= h` on r2
+  float m, neg_m, rho0, c2;  // c2 = soundSpeed^2 (compute.cpp:153)
+  float visc_m;              // dynVisc*m, the left-most product of compute.cpp:204
+  float gx, gy, gz, dt, tank, neg_sigma;
+  float cell;                // cell edge
+  int nx, ny, nz;            // cells per axis of the local grid
+  int cx_off;                // global x-column of local column 0 (slab decomposition)
+  int gnx;                   // global cells per axis (for clamping before the offset)
+  int tension;               // surface-tension term on/off
+};
+
+// Structure-of-arrays particle state in HBM.
+struct State {
+  float *x, *y, *z, *vx, *vy, *vz;
+  int32_t* id;
+};
+
+struct GridBuffers {
+  int32_t* count;      // [ncells]   histogram, left zeroed by the scan
+  int32_t* start;      // [ncells+1] exclusive prefix sum: cell c owns slots [start[c], start[c+1])
+  int32_t* block_sums; // scan scratch
+  int32_t* cell_of;    // [n] cell of particle i (pre-sort order)
+  int32_t* rank_of;    // [n] arrival rank of particle i in its cell (arbitrary, from the atomic)
+  int32_t* src_of;     // [n] provisional slot -> pre-sort index
+  int32_t* id_prov;    // [n] provisional slot -> particle id
+  int32_t* cell_s;     // [n] sorted slot -> cell
+  size_t ncells;
+  size_t scan_blocks;
+};
+
+struct DebugBuffers {
+  float* force;     // [3n] SoA planes fx|fy|fz, sorted order
+  int32_t* ncount;  // [n]
+};
+
+constexpr int kScanItems = 4096;  // cells per scan block
+
+void launch_split_aos(hipStream_t s, const float* pos_aos, const float* vel_aos, int n, State st);
+void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, GridBuffers g);
+void launch_scan(hipStream_t s, GridBuffers g);
+void launch_reorder(hipStream_t s, const State& in, const State& out, int n, GridBuffers g);
+void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, const GridBuffers& g,
+                    float* rho, int32_t* ncount, bool exact);
+void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
+                  const GridBuffers& g, const float* rho, float* force_dbg, bool exact);
+void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos);
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float* rho_s,
+                         const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
+                         float* rho, float* force, int32_t* ncount, int32_t* cell);
+
+}  // namespace sph

@@ -1,0 +1,541 @@
+// gfx950 kernels of the SPH step.  Compile with -ffp-contract=off: the reference's x86-64 object
+// contains no FMA instructions, and the neighbour predicate / cell index must match it bit for bit.
+//
+// Pipeline of one step (reference compute/compute.cpp:120-320 restricted to true neighbours):
+//   k_hash      position -> cell id, per-cell histogram
+//   k_scan_*    exclusive prefix sum over the histogram -> cell start table
+//   k_scatter / k_reorder   counting sort; inside a cell particles end up in ascending id order,
+//               so the summation order of every later pass is a pure function of (positions, ids)
+//   k_density   rho_i = sum_j m*Wpoly6(r_ij)                                   (:131-150)
+//   k_force     pressure + viscosity + gravity + surface tension, symplectic Euler, tank walls
+//                                                                              (:153-319)
+#include "sph_internal.hpp"
+
+namespace sph {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__host__ __device__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
+
+// ---- cell index ---------------------------------------------------------------------------------
+// c = clamp(floorf(x / cell), 0, gn-1) - offset, clamped to the local grid.  True fp32 division:
+// x * (1/cell) rounds differently.  fmaxf(NaN, 0) = 0 keeps NaN positions inside the table.
+__device__ inline int cell_coord(float x, float cell, int gn) {
+  float q = floorf(x / cell);
+  q = fminf(fmaxf(q, 0.0f), (float)(gn - 1));
+  return (int)q;
+}
+__device__ inline int local_col(int cx_global, const DevParams& P) {
+  int c = cx_global - P.cx_off;
+  return c < 0 ? 0 : (c > P.nx - 1 ? P.nx - 1 : c);
+}
+
+// ---- smoothing kernels, reference compute.cpp:41-95 (callers guarantee r <= h) ---------------------
+__device__ inline float w_poly6(const DevParams& P, float r) {  // :61-71
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d3 = d * d * d;
+  return (float)(P.c_poly6 * (double)d3);
+}
+__device__ inline float grad_spiky(const DevParams& P, float r) {  // :50-59
+  float d = P.h - r;
+  float d2 = d * d;
+  return (float)(P.c_spiky_grad * (double)d2);
+}
+__device__ inline float lapl_visc(const DevParams& P, float r) {  // :41-48
+  return (float)(P.c_visc_lapl * (double)(P.h - r));
+}
+__device__ inline float grad_poly6(const DevParams& P, float r) {  // :73-83
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d2 = d * d;
+  return (float)(P.c_poly6_grad * (double)r * (double)d2);
+}
+__device__ inline float lapl_poly6(const DevParams& P, float r) {  // :85-95
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d2 = d * d;
+  float poly = 4.0f * rr * d - d2;
+  return (float)(P.c_poly6_lapl * (double)poly);
+}
+
+// ---- AoS <-> SoA ------------------------------------------------------------------------------------
+__global__ void k_split_aos(const float* __restrict__ pos, const float* __restrict__ vel, int n, State st) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st.x[i] = pos[3 * i + 0];
+  st.y[i] = pos[3 * i + 1];
+  st.z[i] = pos[3 * i + 2];
+  st.vx[i] = vel[3 * i + 0];
+  st.vy[i] = vel[3 * i + 1];
+  st.vz[i] = vel[3 * i + 2];
+  st.id[i] = i;
+}
+
+__global__ void k_gather_aos(State st, int n, float* __restrict__ pos, float* __restrict__ vel) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int i = st.id[s];
+  if (pos) {
+    pos[3 * i + 0] = st.x[s];
+    pos[3 * i + 1] = st.y[s];
+    pos[3 * i + 2] = st.z[s];
+  }
+  if (vel) {
+    vel[3 * i + 0] = st.vx[s];
+    vel[3 * i + 1] = st.vy[s];
+    vel[3 * i + 2] = st.vz[s];
+  }
+}
+
+__global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const float* rho_s,
+                               const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
+                               float* rho, float* force, int32_t* ncount, int32_t* cell) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int i = id[s];
+  if (rho) rho[i] = rho_s[s];
+  if (force) {
+    force[3 * i + 0] = force_s[s];
+    force[3 * i + 1] = force_s[(size_t)n + s];
+    force[3 * i + 2] = force_s[2 * (size_t)n + s];
+  }
+  if (ncount) ncount[i] = ncount_s[s];
+  if (cell) cell[i] = cell_s[s];
+}
+
+// ---- hash + histogram ---------------------------------------------------------------------------------
+__global__ void k_hash(DevParams P, State in, int n, int32_t* __restrict__ cell_of,
+                       int32_t* __restrict__ rank_of, int32_t* __restrict__ count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cx = local_col(cell_coord(in.x[i], P.cell, P.gnx), P);
+  int cy = cell_coord(in.y[i], P.cell, P.ny);
+  int cz = cell_coord(in.z[i], P.cell, P.nz);
+  int c = (cz * P.ny + cy) * P.nx + cx;
+  cell_of[i] = c;
+  rank_of[i] = atomicAdd(&count[c], 1);
+}
+
+// ---- exclusive scan over the cell histogram -----------------------------------------------------------
+__device__ inline int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread block; returns the block total in *total.
+__device__ inline int block_exclusive_scan(int v, int* total) {
+  __shared__ int wsum[kBlock / 64];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = wave_inclusive_scan(v, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; k++) {
+    int s = wsum[k];
+    if (k < w) off += s;
+    tot += s;
+  }
+  *total = tot;
+  __syncthreads();
+  return off + inc - v;
+}
+
+constexpr int kPerThread = kScanItems / kBlock;  // 16 cells per thread
+
+__global__ void __launch_bounds__(kBlock) k_scan_reduce(const int32_t* __restrict__ count, size_t ncells,
+                                                        int32_t* __restrict__ block_sums) {
+  size_t base = (size_t)blockIdx.x * kScanItems + (size_t)threadIdx.x * kPerThread;
+  int s = 0;
+  if (base + kPerThread <= ncells) {
+    const int4* p = reinterpret_cast<const int4*>(count + base);
+#pragma unroll
+    for (int k = 0; k < kPerThread / 4; k++) {
+      int4 v = p[k];
+      s += v.x + v.y + v.z + v.w;
+    }
+  } else {
+    for (int k = 0; k < kPerThread; k++)
+      if (base + k < ncells) s += count[base + k];
+  }
+  int tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// Single block: in-place exclusive scan of the per-block sums.
+__global__ void __launch_bounds__(kBlock) k_scan_top(int32_t* __restrict__ block_sums, int nb) {
+  int carry = 0;
+  for (int base = 0; base < nb; base += kBlock) {
+    int i = base + threadIdx.x;
+    int v = i < nb ? block_sums[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += tot;
+  }
+}
+
+// Writes start[] and leaves count[] zeroed for the next step's histogram.
+__global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ count, size_t ncells,
+                                                       const int32_t* __restrict__ block_sums,
+                                                       int32_t* __restrict__ start) {
+  size_t base = (size_t)blockIdx.x * kScanItems + (size_t)threadIdx.x * kPerThread;
+  int v[kPerThread];
+  int s = 0;
+  bool full = base + kPerThread <= ncells;
+  if (full) {
+    int4* p = reinterpret_cast<int4*>(count + base);
+#pragma unroll
+    for (int k = 0; k < kPerThread / 4; k++) {
+      int4 q = p[k];
+      v[4 * k + 0] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+      p[k] = make_int4(0, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+      v[k] = base + k < ncells ? count[base + k] : 0;
+      if (base + k < ncells) count[base + k] = 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPerThread; k++) s += v[k];
+  int tot;
+  int run = block_sums[blockIdx.x] + block_exclusive_scan(s, &tot);
+  if (full) {
+    int4* o = reinterpret_cast<int4*>(start + base);
+#pragma unroll
+    for (int k = 0; k < kPerThread / 4; k++) {
+      int4 q;
+      q.x = run; run += v[4 * k + 0];
+      q.y = run; run += v[4 * k + 1];
+      q.z = run; run += v[4 * k + 2];
+      q.w = run; run += v[4 * k + 3];
+      o[k] = q;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+      if (base + k < ncells) start[base + k] = run;
+      run += v[k];
+    }
+  }
+  // the thread that owns the last cell also writes the grand total
+  if (base < ncells && base + kPerThread >= ncells) start[ncells] = run;
+}
+
+// ---- counting sort ---------------------------------------------------------------------------------------
+__global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
+                          const int32_t* __restrict__ start, const int32_t* __restrict__ id_in,
+                          int32_t* __restrict__ src_of, int32_t* __restrict__ id_prov) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int slot = start[cell_of[i]] + rank_of[i];
+  src_of[slot] = i;
+  id_prov[slot] = id_in[i];
+}
+
+// Final slot = cell start + number of cell-mates with a smaller id: the in-cell order no longer depends
+// on the order in which the histogram atomics happened to be served.
+__global__ void k_reorder(int n, State in, State out, const int32_t* __restrict__ cell_of,
+                          const int32_t* __restrict__ start, const int32_t* __restrict__ src_of,
+                          const int32_t* __restrict__ id_prov, int32_t* __restrict__ cell_s) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int i = src_of[s];
+  int c = cell_of[i];
+  int my = id_prov[s];
+  int b = start[c], e = start[c + 1];
+  int r = 0;
+  for (int t = b; t < e; t++) r += id_prov[t] < my;
+  int d = b + r;
+  out.x[d] = in.x[i];
+  out.y[d] = in.y[i];
+  out.z[d] = in.z[i];
+  out.vx[d] = in.vx[i];
+  out.vy[d] = in.vy[i];
+  out.vz[d] = in.vz[i];
+  out.id[d] = my;
+  cell_s[d] = c;
+}
+
+// ---- neighbour sweeps --------------------------------------------------------------------------------------
+// The 27-cell stencil of a particle is 9 rows of (up to) 3 x-adjacent cells; with x the fastest-varying
+// cell coordinate each row is ONE contiguous slot range.  Rows are visited dz-major, dy-minor.
+struct Stencil {
+  int b[9], e[9];
+};
+
+__device__ inline void stencil_ranges(const DevParams& P, const int32_t* __restrict__ start, int c, Stencil& st) {
+  int cx = c % P.nx;
+  int t = c / P.nx;
+  int cy = t % P.ny;
+  int cz = t / P.ny;
+  int x0 = cx > 0 ? cx - 1 : 0;
+  int x1 = cx < P.nx - 1 ? cx + 1 : P.nx - 1;
+  int k = 0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; dz++) {
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++, k++) {
+      int y = cy + dy, z = cz + dz;
+      bool ok = y >= 0 && y < P.ny && z >= 0 && z < P.nz;
+      int row = ok ? (z * P.ny + y) * P.nx : 0;
+      st.b[k] = ok ? start[row + x0] : 0;
+      st.e[k] = ok ? start[row + x1 + 1] : 0;
+    }
+  }
+}
+
+__device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
+
+// Density: rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (reference compute.cpp:131-150).
+template <bool EXACT>
+__global__ void __launch_bounds__(kBlock) k_density(DevParams P, State st, int n, const int32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ cell_s, float* __restrict__ rho,
+                                                    int32_t* __restrict__ ncount) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  float xi = st.x[s], yi = st.y[s], zi = st.z[s];
+  Stencil sc;
+  stencil_ranges(P, start, cell_s[s], sc);
+  float acc = 0.0f;
+  int cnt = 0;
+  if (!EXACT) {
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+      for (int j = sc.b[k]; j < sc.e[k]; j++) {
+        float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
+        if (r2 <= P.r2_max) {
+          acc += P.m * w_poly6(P, sqrtf(r2));
+          cnt++;
+        }
+      }
+    }
+  } else {
+    // ascending particle id: the order in which the reference's j loop meets the non-zero terms
+    int last = -1;
+    for (;;) {
+      int best = 0x7fffffff;
+      float best_r2 = 0.0f;
+#pragma unroll 1
+      for (int k = 0; k < 9; k++) {
+        for (int j = sc.b[k]; j < sc.e[k]; j++) {
+          float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
+          int idj = st.id[j];
+          if (r2 <= P.r2_max && idj > last && idj < best) {
+            best = idj;
+            best_r2 = r2;
+          }
+        }
+      }
+      if (best == 0x7fffffff) break;
+      acc += P.m * w_poly6(P, sqrtf(best_r2));
+      cnt++;
+      last = best;
+    }
+  }
+  rho[s] = acc;
+  if (ncount) ncount[s] = cnt;
+}
+
+struct ForceAcc {
+  float px, py, pz;  // pressure          :159
+  float vx, vy, vz;  // viscosity         :192
+  float gx, gy, gz;  // colour gradient   :229
+  float lapl;        // colour laplacian  :230
+};
+
+// One neighbour's contribution to the three pair sums of the reference (:161-179, :194-209, :233-253).
+__device__ inline void pair_terms(const DevParams& P, float dx, float dy, float dz, float r2, float pi,
+                                  float rho_j, float dvx, float dvy, float dvz, ForceAcc& a) {
+  float r = sqrtf(r2);
+  float ux = 0.0f, uy = 0.0f, uz = 0.0f;  // vecNormalize(r, r)  :28-39
+  if (r > 0.0f) {
+    ux = dx / r;
+    uy = dy / r;
+    uz = dz / r;
+  }
+  float pj = P.c2 * (rho_j - P.rho0);                                    // :164
+  float mfp = P.neg_m * (pi + pj) / (2.0f * rho_j) * grad_spiky(P, r);  // :170
+  a.px += mfp * ux;
+  a.py += mfp * uy;
+  a.pz += mfp * uz;
+  float t = P.visc_m * lapl_visc(P, r) / rho_j;  // :204
+  a.vx += dvx * t;
+  a.vy += dvy * t;
+  a.vz += dvz * t;
+  if (P.tension) {
+    float mg = P.m * grad_poly6(P, r) / rho_j;  // :242
+    a.gx += ux * mg;
+    a.gy += uy * mg;
+    a.gz += uz * mg;
+    a.lapl += P.m * lapl_poly6(P, r) / rho_j;  // :252
+  }
+}
+
+template <bool EXACT>
+__global__ void __launch_bounds__(kBlock) k_force(DevParams P, State st, State out, int n,
+                                                  const int32_t* __restrict__ start,
+                                                  const int32_t* __restrict__ cell_s,
+                                                  const float* __restrict__ rho, float* __restrict__ force_dbg) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  float xi = st.x[s], yi = st.y[s], zi = st.z[s];
+  float vxi = st.vx[s], vyi = st.vy[s], vzi = st.vz[s];
+  float rho_i = rho[s];
+  float pi = P.c2 * (rho_i - P.rho0);  // :158
+  Stencil sc;
+  stencil_ranges(P, start, cell_s[s], sc);
+  ForceAcc a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!EXACT) {
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+      for (int j = sc.b[k]; j < sc.e[k]; j++) {
+        float dx = xi - st.x[j], dy = yi - st.y[j], dz = zi - st.z[j];
+        float r2 = dist2(dx, dy, dz);
+        if (r2 <= P.r2_max)
+          pair_terms(P, dx, dy, dz, r2, pi, rho[j], st.vx[j] - vxi, st.vy[j] - vyi, st.vz[j] - vzi, a);
+      }
+    }
+  } else {
+    int last = -1;
+    for (;;) {
+      int best = 0x7fffffff, bj = -1;
+#pragma unroll 1
+      for (int k = 0; k < 9; k++) {
+        for (int j = sc.b[k]; j < sc.e[k]; j++) {
+          float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
+          int idj = st.id[j];
+          if (r2 <= P.r2_max && idj > last && idj < best) {
+            best = idj;
+            bj = j;
+          }
+        }
+      }
+      if (bj < 0) break;
+      float dx = xi - st.x[bj], dy = yi - st.y[bj], dz = zi - st.z[bj];
+      pair_terms(P, dx, dy, dz, dist2(dx, dy, dz), pi, rho[bj], st.vx[bj] - vxi, st.vy[bj] - vyi,
+                 st.vz[bj] - vzi, a);
+      last = best;
+    }
+  }
+  // f_total = (((0 + pressure) + viscosity) + gravity*rho) + tension   (:181-183,:211-213,:220-222,:259-261)
+  float fx = 0.0f + a.px, fy = 0.0f + a.py, fz = 0.0f + a.pz;
+  fx += a.vx;
+  fy += a.vy;
+  fz += a.vz;
+  fx += P.gx * rho_i;
+  fy += P.gy * rho_i;
+  fz += P.gz * rho_i;
+  if (P.tension) {
+    float len = sqrtf(a.gx * a.gx + a.gy * a.gy + a.gz * a.gz);  // vecNormalize(gradcolor)  :255
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    if (len > 0.0f) {
+      nx = a.gx / len;
+      ny = a.gy / len;
+      nz = a.gz / len;
+    }
+    float t = P.neg_sigma * a.lapl;  // :257
+    fx += t * nx;
+    fy += t * ny;
+    fz += t * nz;
+  }
+  if (force_dbg) {
+    force_dbg[s] = fx;
+    force_dbg[(size_t)n + s] = fy;
+    force_dbg[2 * (size_t)n + s] = fz;
+  }
+  // symplectic Euler (:265-280)
+  float scl = P.dt / rho_i;
+  vxi += fx * scl;
+  vyi += fy * scl;
+  vzi += fz * scl;
+  xi = xi + vxi * P.dt;
+  yi = yi + vyi * P.dt;
+  zi = zi + vzi * P.dt;
+  // tank walls, damping 1 (:286-319)
+  if (xi < 0.0f) { xi = 0.0f; vxi = -1.0f * vxi; }
+  if (xi > P.tank) { xi = P.tank; vxi = -1.0f * vxi; }
+  if (yi < 0.0f) { yi = 0.0f; vyi = -1.0f * vyi; }
+  if (yi > P.tank) { yi = P.tank; vyi = -1.0f * vyi; }
+  if (zi < 0.0f) { zi = 0.0f; vzi = -1.0f * vzi; }
+  if (zi > P.tank) { zi = P.tank; vzi = -1.0f * vzi; }
+  out.x[s] = xi;
+  out.y[s] = yi;
+  out.z[s] = zi;
+  out.vx[s] = vxi;
+  out.vy[s] = vyi;
+  out.vz[s] = vzi;
+}
+
+}  // namespace
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+void launch_split_aos(hipStream_t s, const float* pos_aos, const float* vel_aos, int n, State st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_split_aos, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, pos_aos, vel_aos, n, st);
+}
+
+void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, GridBuffers g) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_hash, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, in, n, g.cell_of, g.rank_of, g.count);
+}
+
+void launch_scan(hipStream_t s, GridBuffers g) {
+  int nb = (int)g.scan_blocks;
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, g.block_sums, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start);
+}
+
+void launch_reorder(hipStream_t s, const State& in, const State& out, int n, GridBuffers g) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, g.cell_of, g.rank_of, g.start,
+                     in.id, g.src_of, g.id_prov);
+  hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.cell_of, g.start,
+                     g.src_of, g.id_prov, g.cell_s);
+}
+
+void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, const GridBuffers& g, float* rho,
+                    int32_t* ncount, bool exact) {
+  if (n <= 0) return;
+  dim3 grid(div_up(n, kBlock)), block(kBlock);
+  if (exact)
+    hipLaunchKernelGGL(k_density<true>, grid, block, 0, s, P, st, n, g.start, g.cell_s, rho, ncount);
+  else
+    hipLaunchKernelGGL(k_density<false>, grid, block, 0, s, P, st, n, g.start, g.cell_s, rho, ncount);
+}
+
+void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
+                  const GridBuffers& g, const float* rho, float* force_dbg, bool exact) {
+  if (n <= 0) return;
+  dim3 grid(div_up(n, kBlock)), block(kBlock);
+  if (exact)
+    hipLaunchKernelGGL(k_force<true>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg);
+  else
+    hipLaunchKernelGGL(k_force<false>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg);
+}
+
+void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_aos, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, st, n, pos_aos, vel_aos);
+}
+
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float* rho_s, const float* force_s,
+                         const int32_t* ncount_s, const int32_t* cell_s, float* rho, float* force,
+                         int32_t* ncount, int32_t* cell) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_debug, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, id, n, rho_s, force_s, ncount_s,
+                     cell_s, rho, force, ncount, cell);
+}
+
+}  // namespace sph

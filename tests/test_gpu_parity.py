@@ -1,0 +1,338 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libsph_amd.so), against
+ (1) the golden vectors generated from the reference's own compute.cpp,
+ (2) the CPU oracle on fresh seeded inputs,
+ (3) size-independent properties at the benchmark's full size (1M-particle dam break).
+
+Bars:
+  * cell ids and neighbour counts: bit-exact, always;
+  * SPH_FLAG_EXACT_ORDER: densities, forces, positions, velocities bit-exact vs the reference,
+    at every stored step (same terms, same summation order);
+  * default (stencil-order) path: max|a-b|/max|b| <= 1e-5 after one step for density, force
+    density, position and velocity; after k steps the error is bounded against the reference's
+    own summation-order noise floor stored with each golden case (the system is chaotic: the
+    reference disagrees with a permuted copy of itself by ~x10 per 5 steps).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, golden_case_names, load_golden, max_rel
+
+from sph_amd import capi, scenes
+from sph_amd.params import (SPH_FLAG_EXACT_ORDER, SPH_FLAG_KEEP_DEBUG, SPH_FLAG_SURFACE_TENSION,
+                            default_params)
+
+pytestmark = pytest.mark.gpu
+
+TOL_ONE_STEP = 1e-5
+STEPS = (1, 2, 5, 10)
+DBG = SPH_FLAG_SURFACE_TENSION | SPH_FLAG_KEEP_DEBUG
+
+
+def run_gpu(params, pos, vel, nsteps, n_max=None):
+    with capi.Simulation(params, n_max=n_max or max(1, pos.shape[0])) as sim:
+        sim.upload(pos, vel)
+        sim.step(nsteps)
+        out = sim.download()
+        dbg = sim.download_debug() if nsteps > 0 and (params.flags & SPH_FLAG_KEEP_DEBUG) else None
+    return out, dbg
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_exact_order_bit_exact_vs_reference(name):
+    g = load_golden(name)
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    with capi.Simulation(p, n_max=g["pos0"].shape[0]) as sim:
+        sim.upload(g["pos0"], g["vel0"])
+        for k in range(1, 11):
+            sim.step(1)
+            if k == 1:
+                rho, force, nc, cell = sim.download_debug()
+                assert np.array_equal(cell, g["cell0"]), "cell ids"
+                assert np.array_equal(nc, g["ncount0"]), "neighbour counts"
+                assert bits_equal(rho, g["rho1"]), "densities"
+                assert bits_equal(force, g["force1"]), "force densities"
+            if k in STEPS:
+                pos, vel = sim.download()
+                assert bits_equal(pos, g[f"pos_{k}"]), f"positions after {k} steps"
+                assert bits_equal(vel, g[f"vel_{k}"]), f"velocities after {k} steps"
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_stencil_order_within_tolerance_vs_reference(name):
+    g = load_golden(name)
+    p = default_params(flags=DBG)
+    with capi.Simulation(p, n_max=g["pos0"].shape[0]) as sim:
+        sim.upload(g["pos0"], g["vel0"])
+        for k in range(1, 11):
+            sim.step(1)
+            if k == 1:
+                rho, force, nc, cell = sim.download_debug()
+                assert np.array_equal(cell, g["cell0"])
+                assert np.array_equal(nc, g["ncount0"])
+                assert max_rel(rho, g["rho1"]) <= TOL_ONE_STEP
+                assert max_rel(force, g["force1"]) <= TOL_ONE_STEP
+            if k in STEPS:
+                pos, vel = sim.download()
+                # bounded drift: one-step tolerance, or a multiple of the reference's own
+                # permutation noise at this step count, whichever is larger
+                tol_p = max(TOL_ONE_STEP, 50.0 * float(g[f"noise_pos_{k}"]))
+                tol_v = max(TOL_ONE_STEP, 50.0 * float(g[f"noise_vel_{k}"]))
+                if k == 1:
+                    tol_p = tol_v = TOL_ONE_STEP
+                assert max_rel(pos, g[f"pos_{k}"]) <= tol_p, f"positions after {k} steps"
+                assert max_rel(vel, g[f"vel_{k}"]) <= tol_v, f"velocities after {k} steps"
+
+
+@pytest.mark.parametrize("n,seed", [(1, 5), (17, 6), (1000, 7), (4096, 8)])
+def test_fresh_seeds_vs_oracle(oracle, n, seed):
+    pos, vel = scenes.random_block(n, tank_size=0.2154 * 0.6, seed=seed)
+    rng = np.random.default_rng(seed)
+    vel = ((rng.random(vel.shape, dtype=np.float32) - np.float32(0.5))).astype(np.float32)
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    po, vo = pos.copy(), vel.copy()
+    with capi.Simulation(p, n_max=n) as sim:
+        sim.upload(pos, vel)
+        for _ in range(4):
+            nc_o = oracle.neighbor_counts(p, po)
+            cell_o = oracle.cell_ids(p, po)
+            rho_o, f_o = oracle.step_allpairs(p, po, vo, want_debug=True)
+            sim.step(1)
+            rho, f, nc, cell = sim.download_debug()
+            gp, gv = sim.download()
+            assert np.array_equal(nc, nc_o) and np.array_equal(cell, cell_o)
+            assert bits_equal(rho, rho_o) and bits_equal(f, f_o)
+            assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_stencil_order_matches_grid_twin_bitwise(oracle):
+    """The default path's summation order is a pure function of (positions, ids): stencil rows
+    dz-major/dy-minor, cells ascending in x, ascending id inside a cell.  The CPU grid twin sums
+    in that same order, so the two agree to the last bit — which makes the twin a bit-level
+    oracle at sizes the all-pairs oracle cannot reach."""
+    pos, vel = scenes.jittered_lattice(20, 20, 20, seed=3)
+    p = default_params(flags=DBG)
+    po, vo = pos.copy(), vel.copy()
+    with capi.Simulation(p, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        for _ in range(5):
+            rho_o, f_o, nc_o = oracle.step_grid(p, po, vo, order=0, want_debug=True)
+            sim.step(1)
+            rho, f, nc, _ = sim.download_debug()
+            gp, gv = sim.download()
+            assert np.array_equal(nc, nc_o)
+            assert bits_equal(rho, rho_o) and bits_equal(f, f_o)
+            assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_non_default_parameters(oracle):
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    p.h = 0.0125
+    p.tank_size = 0.3
+    p.dyn_visc = 0.35
+    p.rho0 = 550.0
+    p.sound_speed = 1.3
+    p.timestep = 0.004
+    p.gravity[0], p.gravity[1], p.gravity[2] = 2.5, -9.6, 0.4
+    pos, vel = scenes.jittered_lattice(9, 9, 9, seed=21)
+    po, vo = pos.copy(), vel.copy()
+    (gp, gv), (rho, f, nc, cell) = run_gpu(p, pos, vel, 1)
+    nc_o, cell_o = oracle.neighbor_counts(p, po), oracle.cell_ids(p, po)
+    rho_o, f_o = oracle.step_allpairs(p, po, vo, want_debug=True)
+    assert np.array_equal(nc, nc_o) and np.array_equal(cell, cell_o)
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_surface_tension_switch(oracle):
+    pos, vel = scenes.jittered_lattice(8, 8, 8, seed=4)
+    on = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    off = default_params(flags=SPH_FLAG_KEEP_DEBUG | SPH_FLAG_EXACT_ORDER)
+    (_, _), (_, f_on, _, _) = run_gpu(on, pos, vel, 1)
+    (_, _), (_, f_off, _, _) = run_gpu(off, pos, vel, 1)
+    po, vo = pos.copy(), vel.copy()
+    _, f_o = oracle.step_allpairs(off, po, vo, want_debug=True)
+    assert bits_equal(f_off, f_o)
+    assert max_rel(f_on, f_off) > 1e-3, "the tension term is comparable to gravity; it must show"
+
+
+# ---- edge cases -----------------------------------------------------------------------------------
+
+def test_empty_and_single():
+    p = default_params(flags=DBG)
+    with capi.Simulation(p, n_max=8) as sim:
+        sim.upload(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+        sim.step(3)
+        pos, vel = sim.download()
+        assert pos.shape == (0, 3)
+        sim.upload(np.array([[0.1, 0.1, 0.1]], np.float32), np.zeros((1, 3), np.float32))
+        sim.step(1)
+        pos, vel = sim.download()
+        assert vel[0, 1] == pytest.approx(-0.05, rel=1e-6)
+        rho, _, nc, _ = sim.download_debug()
+        assert nc[0] == 1 and abs(rho[0] - 321.843) < 1e-2
+
+
+def test_capacity_and_state_errors():
+    p = default_params()
+    with capi.Simulation(p, n_max=4) as sim:
+        with pytest.raises(capi.SphError) as e:
+            sim.step(1)
+        assert e.value.code == 5  # SPH_ERR_STATE
+        with pytest.raises(capi.SphError) as e:
+            sim.upload(np.zeros((5, 3), np.float32), np.zeros((5, 3), np.float32))
+        assert e.value.code == 4  # SPH_ERR_CAPACITY
+        sim.upload(np.full((4, 3), 0.1, np.float32), np.zeros((4, 3), np.float32))
+        with pytest.raises(capi.SphError):
+            sim.download_debug()  # no step yet
+        big = p.copy()
+        big.tank_size = 1.0
+        with pytest.raises(capi.SphError) as e:
+            sim.set_params(big)
+        assert e.value.code == 4
+
+
+def test_all_particles_in_one_cell(oracle):
+    """Maximum collisions: every particle hashes to the same cell (and many coincide)."""
+    rng = np.random.default_rng(1)
+    pos = (np.float32(0.105) + rng.random((300, 3), dtype=np.float32) * np.float32(0.004)).astype(np.float32)
+    pos[:40] = pos[0]
+    vel = np.zeros_like(pos)
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    po, vo = pos.copy(), vel.copy()
+    (gp, gv), (rho, f, nc, cell) = run_gpu(p, pos, vel, 1)
+    rho_o, f_o = oracle.step_allpairs(p, po, vo, want_debug=True)
+    assert len(np.unique(cell)) == 1 and np.all(nc == 300)
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po)
+
+
+def test_particles_outside_the_tank(oracle):
+    """Positions beyond the walls are legal inputs for the reference (all-pairs); cell indices
+    clamp, which only merges cells, so the stencil still covers every neighbour pair."""
+    pos, vel = scenes.wall_contact(900, seed=3)
+    pos[:50] += np.float32(0.03)
+    pos[50:100] -= np.float32(0.025)
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    po, vo = pos.copy(), vel.copy()
+    nc_o = oracle.neighbor_counts(p, po)
+    (gp, gv), (rho, f, nc, cell) = run_gpu(p, pos, vel, 1)
+    rho_o, f_o = oracle.step_allpairs(p, po, vo, want_debug=True)
+    assert np.array_equal(nc, nc_o)
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po) and bits_equal(gv, vo)
+    assert gp.min() >= 0.0 and gp.max() <= np.float32(p.tank_size)
+
+
+def test_reupload_smaller_after_larger(oracle):
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    a, av = scenes.random_block(2000, seed=1)
+    b, bv = scenes.random_block(300, tank_size=0.05, seed=2)
+    with capi.Simulation(p, n_max=2000) as sim:
+        sim.upload(a, av)
+        sim.step(2)
+        sim.upload(b, bv)
+        sim.step(1)
+        gp, gv = sim.download()
+    po, vo = b.copy(), bv.copy()
+    oracle.step_allpairs(p, po, vo)
+    assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_gravity_change_between_steps(oracle):
+    """The reference's a_gravity global may be edited between calls (sloshing)."""
+    p = default_params(flags=DBG | SPH_FLAG_EXACT_ORDER)
+    pos, vel = scenes.jittered_lattice(7, 7, 7, seed=9)
+    po, vo = pos.copy(), vel.copy()
+    with capi.Simulation(p, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        for s in range(4):
+            g = scenes.sloshing_gravity(s * 50)
+            q = p.copy()
+            q.gravity[0], q.gravity[1], q.gravity[2] = g
+            sim.set_params(q)
+            sim.step(1)
+            oracle.step_allpairs(q, po, vo)
+        gp, gv = sim.download()
+    assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_one_call_update_particles(oracle):
+    """sph_update_particles = the reference's updateParticles(particles, velocities, n)."""
+    pos, vel = scenes.random_block(1200, tank_size=0.1, seed=4)
+    p = default_params()
+    po, vo = pos.copy(), vel.copy()
+    for _ in range(3):
+        capi.update_particles(pos, vel, p)
+        oracle.step_allpairs(p, po, vo)
+    assert max_rel(pos, po) <= TOL_ONE_STEP * 3 and max_rel(vel, vo) <= 1e-4
+
+
+def test_device_resident_io():
+    torch = pytest.importorskip("torch")
+    pos, vel = scenes.random_block(5000, seed=2)
+    p = default_params()
+    dp, dv = torch.from_numpy(pos).cuda(), torch.from_numpy(vel).cuda()
+    op, ov = torch.empty_like(dp), torch.empty_like(dv)
+    with capi.Simulation(p, n_max=5000) as sim:
+        sim.upload_device(dp.data_ptr(), dv.data_ptr(), 5000)
+        sim.step(2)
+        sim.download_device(op.data_ptr(), ov.data_ptr())
+        hp, hv = sim.download()
+    assert bits_equal(op.cpu().numpy(), hp) and bits_equal(ov.cpu().numpy(), hv)
+
+
+def test_run_to_run_determinism():
+    pos, vel, p = scenes.dam_break(40)
+    outs = []
+    for _ in range(2):
+        (gp, gv), _ = run_gpu(p, pos, vel, 5)
+        outs.append((gp, gv))
+    assert bits_equal(outs[0][0], outs[1][0]) and bits_equal(outs[0][1], outs[1][1])
+
+
+# ---- full benchmark size: 1M-particle dam break ------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def dam_1m():
+    return scenes.dam_break(100)
+
+
+def test_1m_stencil_vs_exact_order(dam_1m):
+    pos, vel, p = dam_1m
+    fast = p.copy(); fast.flags = DBG
+    exact = p.copy(); exact.flags = DBG | SPH_FLAG_EXACT_ORDER
+    (fp, fv), (frho, ff, fnc, fcell) = run_gpu(fast, pos, vel, 1)
+    (ep, ev), (erho, ef, enc, ecell) = run_gpu(exact, pos, vel, 1)
+    assert np.array_equal(fnc, enc) and np.array_equal(fcell, ecell)
+    assert max_rel(frho, erho) <= TOL_ONE_STEP
+    assert max_rel(ff, ef) <= TOL_ONE_STEP
+    assert max_rel(fp, ep) <= TOL_ONE_STEP and max_rel(fv, ev) <= TOL_ONE_STEP
+    # neighbour relation is symmetric: the pair count is even once self-pairs are removed
+    assert int((enc.astype(np.int64) - 1).sum()) % 2 == 0
+    assert enc.min() >= 1
+
+
+def test_1m_matches_grid_twin_bitwise(oracle, dam_1m):
+    pos, vel, p = dam_1m
+    q = p.copy(); q.flags = DBG
+    po, vo = pos.copy(), vel.copy()
+    with capi.Simulation(q, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        for _ in range(2):
+            cell_o = oracle.cell_ids(q, po)
+            rho_o, f_o, nc_o = oracle.step_grid(q, po, vo, order=0, want_debug=True)
+            sim.step(1)
+            rho, f, nc, cell = sim.download_debug()
+            assert np.array_equal(nc, nc_o) and np.array_equal(cell, cell_o)
+            assert bits_equal(rho, rho_o) and bits_equal(f, f_o)
+        gp, gv = sim.download()
+    assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_1m_long_run_stays_in_tank(dam_1m):
+    pos, vel, p = dam_1m
+    (gp, gv), _ = run_gpu(p, pos, vel, 100)
+    assert np.isfinite(gp).all() and np.isfinite(gv).all()
+    assert gp.min() >= 0.0 and gp.max() <= np.float32(p.tank_size)
+    # gravity pulls the block down and it spreads: centre of mass drops, x-extent grows
+    assert gp[:, 1].mean() < pos[:, 1].mean()
+    assert gp[:, 0].max() > pos[:, 0].max()
