@@ -137,7 +137,7 @@ int sph_download_device(sph_context* ctx, float* d_pos_aos, float* d_vel_aos);
  *   rho[n]      densities                          (compute.cpp:148)
  *   force[3n]   total force density f_total        (compute.cpp:122, before integration)
  *   ncount[n]   #{j : sqrtf(r2_ij) <= h}, self included
- *   cell[n]     linear cell id (cz*ny + cy)*nx + cx of the position the step started from
+ *   cell[n]     linear cell id (cx*ny + cy)*nz + cz (z fastest) of the position the step started from
  * force and ncount need SPH_FLAG_KEEP_DEBUG.
  */
 int sph_download_debug(sph_context* ctx, float* rho, float* force, int32_t* ncount,
@@ -169,6 +169,70 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
  */
 int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos_aos,
                           float* vel_aos, int n);
+
+/* ---- slab decomposition (one context per GPU / per process rank) -----------------------------
+ *
+ * The reference is a single shared-memory process (OpenMP only); it has no counterpart of this
+ * section.  Interactions reach no further than h (the kernels vanish beyond it, reference
+ * compute.cpp:44,53,64,76,88), so the tank is cut into slabs along x on cell-column boundaries.
+ * A slab context owns the global cell columns [col_lo, col_hi) and keeps two ghost columns on
+ * each side: the inner one gets its density recomputed locally (it needs the outer one), so a
+ * step needs ONE neighbour exchange, which carries migrants and ghosts together:
+ *
+ *   sph_slab_pack     every particle within two columns of (or beyond) a face -> record buffer
+ *   <exchange>        caller moves the buffers to the neighbouring ranks (RCCL send/recv, ...)
+ *   sph_slab_append   received records join the particle set
+ *   sph_step(ctx, 1)  sort over the local grid, density on own+1 columns, forces/integration on
+ *                     own columns; afterwards the context holds exactly the particles whose
+ *                     pre-step column was in [col_lo, col_hi)
+ *
+ * Ownership is decided by column alone, so a migrant is integrated by exactly one rank, and the
+ * per-particle summation order is the same as on a single GPU: an N-slab run is bit-identical
+ * to the 1-GPU run.  Slabs must be at least 4 columns wide.
+ * A record is 7 consecutive 32-bit words: x, y, z, vx, vy, vz, id.
+ */
+#define SPH_SLAB_RECORD_WORDS 7
+#define SPH_SLAB_MIN_COLUMNS 4
+
+/* Cells per axis of the global grid for these parameters. */
+int sph_global_cells(const sph_params* params, int* cells_per_axis);
+
+/* Like sph_create, for the slab [col_lo, col_hi); cols_capacity (>= col_hi - col_lo) bounds how
+ * wide the slab may become through sph_slab_set_columns. */
+int sph_slab_create(const sph_params* params, int n_max, int device, int col_lo, int col_hi,
+                    int cols_capacity, sph_context** out);
+/* Move the slab's faces (load balancing).  All ranks must switch between the same two steps and
+ * a face may move by at most one column per step. */
+int sph_slab_set_columns(sph_context* ctx, int col_lo, int col_hi);
+int sph_slab_get_columns(const sph_context* ctx, int* col_lo, int* col_hi, int* global_cols);
+
+/* Host -> HBM with explicit global particle ids (int32). */
+int sph_slab_upload(sph_context* ctx, const float* pos_aos, const float* vel_aos,
+                    const int32_t* ids, int n);
+/* HBM -> host in storage order with ids; *n_out particles (<= capacity). */
+int sph_slab_download(sph_context* ctx, float* pos_aos, float* vel_aos, int32_t* ids,
+                      int capacity, int* n_out);
+/* Intermediates of the last step for the particles sph_slab_download returns, same order. */
+int sph_slab_download_debug(sph_context* ctx, float* rho, float* force, int32_t* ncount,
+                            int32_t* cell, int capacity);
+
+/* Fill the caller's DEVICE buffers (capacity records each) with the records the left / right
+ * neighbour needs; counts come back on the host.  Pass NULL for a face at the tank wall. */
+int sph_slab_pack(sph_context* ctx, float* d_rec_left, float* d_rec_right, int capacity,
+                  int* n_left, int* n_right);
+/* Add n_rec records from a DEVICE buffer to the particle set. */
+int sph_slab_append(sph_context* ctx, const float* d_rec, int n_rec);
+
+/* Particles per OWN column at the last sort (host array, ncols = col_hi - col_lo entries). */
+int sph_slab_column_counts(sph_context* ctx, int32_t* counts, int capacity, int* ncols);
+/* Total number of particles dropped so far because they left the local grid (should be 0). */
+int sph_slab_lost(sph_context* ctx, int64_t* lost);
+
+/* The HIP stream (hipStream_t) all of the context's work is issued on; sph_set_stream makes the
+ * context issue on a caller-owned stream instead (e.g. the stream a communication library
+ * orders its transfers against). */
+int sph_get_stream(sph_context* ctx, void** stream);
+int sph_set_stream(sph_context* ctx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -307,7 +307,7 @@ void sph_oracle_cell_ids(const sph_params* p, const float* pos, int n, int32_t* 
     int cx = cell_coord(pos[3 * i + 0], k.cell_size, k.ncell);
     int cy = cell_coord(pos[3 * i + 1], k.cell_size, k.ncell);
     int cz = cell_coord(pos[3 * i + 2], k.cell_size, k.ncell);
-    out[i] = (cz * k.ncell + cy) * k.ncell + cx;
+    out[i] = (cx * k.ncell + cy) * k.ncell + cz;
   }
 }
 
@@ -332,15 +332,15 @@ static int gather_neighbors(const ctx_t* c, const float* spos, const int32_t* si
   int cy = cell_coord(spos[3 * s + 1], c->k.cell_size, nc);
   int cz = cell_coord(spos[3 * s + 2], c->k.cell_size, nc);
   int k = 0;
-  for (int dz = -1; dz <= 1; dz++) {
-    int z = cz + dz;
-    if (z < 0 || z >= nc) continue;
+  for (int dx = -1; dx <= 1; dx++) {
+    int x = cx + dx;
+    if (x < 0 || x >= nc) continue;
     for (int dy = -1; dy <= 1; dy++) {
       int y = cy + dy;
       if (y < 0 || y >= nc) continue;
-      int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < nc - 1 ? cx + 1 : nc - 1;
-      int row = (z * nc + y) * nc;
-      for (int j = cstart[row + x0]; j < cstart[row + x1 + 1]; j++) {
+      int z0 = cz > 0 ? cz - 1 : 0, z1 = cz < nc - 1 ? cz + 1 : nc - 1;
+      int row = (x * nc + y) * nc;
+      for (int j = cstart[row + z0]; j < cstart[row + z1 + 1]; j++) {
         float d[3];
         sep(spos, s, j, d);
         float r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];

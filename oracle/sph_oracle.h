@@ -57,12 +57,13 @@ void sph_oracle_step_allpairs(const sph_params* p, float* pos, float* vel, int n
 /* #{j : sqrtf(r2_ij) <= h}, self included, with the reference's r2 arithmetic (:140-144). */
 void sph_oracle_neighbor_counts(const sph_params* p, const float* pos, int n, int32_t* out);
 
-/* Linear cell id (cz*nc + cy)*nc + cx with c = clamp(floorf(x / cell_size), 0, nc-1). */
+/* Linear cell id (cx*nc + cy)*nc + cz (z fastest, x slowest: x is the slab-decomposition axis)
+ * with c = clamp(floorf(x / cell_size), 0, nc-1). */
 void sph_oracle_cell_ids(const sph_params* p, const float* pos, int n, int32_t* out);
 
 /*
  * Uniform-grid twin: same physics restricted to the 27-cell stencil.
- *   order = 0: neighbours are summed in stencil order (dz,dy outer; cells ascending in x;
+ *   order = 0: neighbours are summed in stencil order (dx,dy outer; cells ascending in z;
  *              ascending id inside a cell) — the order of the HIP fast path;
  *   order = 1: ascending particle id — bit-identical to sph_oracle_step_allpairs.
  * ids[n] may be NULL (id = index).  ncount_out (may be NULL) gets neighbour counts.

@@ -40,7 +40,24 @@ _SIGNATURES = [
     ("sph_reset_timings", C.c_int, [_CTX]),
     ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
     ("sph_fill_random_block", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
+    # slab decomposition
+    ("sph_global_cells", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("sph_slab_create", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_CTX)]),
+    ("sph_slab_set_columns", C.c_int, [_CTX, C.c_int, C.c_int]),
+    ("sph_slab_get_columns", C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("sph_slab_upload", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_slab_download", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("sph_slab_download_debug", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_slab_pack", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("sph_slab_append", C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    ("sph_slab_column_counts", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("sph_slab_lost", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
+    ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
+    ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
 ]
+
+RECORD_WORDS = 7      # SPH_SLAB_RECORD_WORDS: x, y, z, vx, vy, vz, id
+MIN_SLAB_COLUMNS = 4  # SPH_SLAB_MIN_COLUMNS
 
 _lib = None
 
@@ -170,6 +187,134 @@ class Simulation:
         _check(self.lib.sph_download_debug(self._ctx, rho.ctypes.data, f.ctypes.data if force else None,
                                            nc.ctypes.data if ncount else None, cell.ctypes.data))
         return rho, f, nc, cell
+
+    def enable_timing(self, on=True):
+        _check(self.lib.sph_enable_timing(self._ctx, 1 if on else 0))
+
+    def reset_timings(self):
+        _check(self.lib.sph_reset_timings(self._ctx))
+
+    def timings(self):
+        t = SphTimings()
+        _check(self.lib.sph_get_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in SphTimings._fields_}
+
+
+def global_cells(params):
+    n = C.c_int()
+    _check(load().sph_global_cells(C.byref(params), C.byref(n)))
+    return n.value
+
+
+class SlabSimulation:
+    """One slab of the x-decomposition on one GPU (one per process rank).
+
+    Record buffers handed to / returned by pack() and append() are torch CUDA tensors of shape
+    [k, RECORD_WORDS] float32: torch only provides the device memory and the transport.
+    """
+
+    def __init__(self, params, n_max, col_lo, col_hi, cols_capacity=0, device=0, rec_capacity=None):
+        import torch
+        self.torch = torch
+        self.lib = load()
+        self.params = params.copy()
+        self._ctx = _CTX()
+        _check(self.lib.sph_slab_create(C.byref(self.params), int(n_max), int(device), int(col_lo), int(col_hi),
+                                        int(cols_capacity), C.byref(self._ctx)))
+        self.n_max = int(n_max)
+        self.device = torch.device("cuda", device)
+        self.rec_capacity = int(rec_capacity if rec_capacity is not None else max(1024, n_max // 4))
+        self._send_left = torch.empty((self.rec_capacity, RECORD_WORDS), dtype=torch.float32, device=self.device)
+        self._send_right = torch.empty((self.rec_capacity, RECORD_WORDS), dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if self._ctx:
+            self.lib.sph_destroy(self._ctx)
+            self._ctx = _CTX()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- columns ----------------------------------------------------------------------------------
+    def columns(self):
+        lo, hi, g = C.c_int(), C.c_int(), C.c_int()
+        _check(self.lib.sph_slab_get_columns(self._ctx, C.byref(lo), C.byref(hi), C.byref(g)))
+        return lo.value, hi.value, g.value
+
+    def set_columns(self, lo, hi):
+        _check(self.lib.sph_slab_set_columns(self._ctx, int(lo), int(hi)))
+
+    def column_counts(self):
+        lo, hi, _ = self.columns()
+        out = np.empty(hi - lo, np.int32)
+        n = C.c_int()
+        _check(self.lib.sph_slab_column_counts(self._ctx, out.ctypes.data, out.size, C.byref(n)))
+        return out
+
+    # -- state ------------------------------------------------------------------------------------
+    @property
+    def n(self):
+        return int(self.lib.sph_num_particles(self._ctx))
+
+    def upload(self, pos, vel, ids):
+        pos, vel = _f32(pos), _f32(vel)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        _check(self.lib.sph_slab_upload(self._ctx, pos.ctypes.data, vel.ctypes.data, ids.ctypes.data, ids.size))
+
+    def download(self):
+        cap = self.n_max
+        pos = np.empty((cap, 3), np.float32)
+        vel = np.empty((cap, 3), np.float32)
+        ids = np.empty(cap, np.int32)
+        n = C.c_int()
+        _check(self.lib.sph_slab_download(self._ctx, pos.ctypes.data, vel.ctypes.data, ids.ctypes.data, cap,
+                                          C.byref(n)))
+        return pos[:n.value], vel[:n.value], ids[:n.value]
+
+    def download_debug(self):
+        cap = self.n_max
+        rho = np.empty(cap, np.float32)
+        f = np.empty((cap, 3), np.float32)
+        nc = np.empty(cap, np.int32)
+        cell = np.empty(cap, np.int32)
+        _check(self.lib.sph_slab_download_debug(self._ctx, rho.ctypes.data, f.ctypes.data, nc.ctypes.data,
+                                                cell.ctypes.data, cap))
+        n = self.n
+        return rho[:n], f[:n], nc[:n], cell[:n]
+
+    def lost(self):
+        v = C.c_int64()
+        _check(self.lib.sph_slab_lost(self._ctx, C.byref(v)))
+        return v.value
+
+    # -- the per-step protocol -----------------------------------------------------------------------
+    def pack(self):
+        """Records for the (left, right) neighbour: views of this object's send buffers."""
+        nl, nr = C.c_int(), C.c_int()
+        _check(self.lib.sph_slab_pack(self._ctx, self._send_left.data_ptr(), self._send_right.data_ptr(),
+                                      self.rec_capacity, C.byref(nl), C.byref(nr)))
+        return self._send_left[:nl.value], self._send_right[:nr.value]
+
+    def append(self, records):
+        if records is None or records.shape[0] == 0:
+            return
+        assert records.is_cuda and records.dtype == self.torch.float32 and records.is_contiguous()
+        _check(self.lib.sph_slab_append(self._ctx, records.data_ptr(), int(records.shape[0])))
+
+    def step(self, nsteps=1):
+        _check(self.lib.sph_step(self._ctx, int(nsteps)))
+
+    def sync(self):
+        _check(self.lib.sph_sync(self._ctx))
+
+    def use_stream(self, stream_ptr):
+        _check(self.lib.sph_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    def empty_records(self, n):
+        return self.torch.empty((n, RECORD_WORDS), dtype=self.torch.float32, device=self.device)
 
     def enable_timing(self, on=True):
         _check(self.lib.sph_enable_timing(self._ctx, 1 if on else 0))

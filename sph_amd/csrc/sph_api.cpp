@@ -54,6 +54,17 @@ struct sph_context {
   float *stage_pos = nullptr, *stage_vel = nullptr;  // AoS staging in HBM, 3*n_max floats each
   void* stage_dbg = nullptr;                         // 6*n_max words for debug downloads
   bool uploaded = false, stepped = false;
+  // slab decomposition: this context owns global x-columns [col_lo, col_hi) of gn; single-GPU = [0, gn)
+  bool slab = false;
+  bool own_stream = true;
+  int gn = 0, col_lo = 0, col_hi = 0, cols_capacity = 0;
+  int n_last_own = 0;                 // particles integrated by the last step (debug downloads)
+  int dbg_stride = 0;                 // plane stride of dbg.force = particle count the last step was launched with
+  int32_t* d_counters = nullptr;      // [0],[1] pack counters  [2] own count  [3] trash count after a step
+  int32_t* h_counters = nullptr;      // pinned mirror
+  int32_t* d_colcounts = nullptr;     // [cols_capacity + 4]
+  bool n_pending = false;             // true count of `cur` still travelling to h_counters[2]
+  int64_t lost = 0;
   bool timing = false;
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
@@ -199,36 +210,76 @@ void free_state(State* s) {
   *s = State{};
 }
 
-int set_grid(sph_context* c, const sph_params* p) {
+int set_grid(sph_context* c, const sph_params* p, int col_lo, int col_hi) {
   int gn = cells_per_axis(p);
   if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
-  size_t ncells = (size_t)gn * gn * gn;
+  if (!c->slab) { col_lo = 0; col_hi = gn; }
+  if (col_lo < 0 || col_hi > gn || col_hi <= col_lo)
+    return fail(SPH_ERR_INVALID, "slab columns [%d, %d) outside the %d-column grid", col_lo, col_hi, gn);
+  if (c->slab && col_hi - col_lo < SPH_SLAB_MIN_COLUMNS && !(col_lo == 0 && col_hi == gn))
+    return fail(SPH_ERR_INVALID, "slab [%d, %d) is narrower than %d columns", col_lo, col_hi, SPH_SLAB_MIN_COLUMNS);
+  // two ghost columns per interior face
+  const int g_lo = col_lo - 2 < 0 ? 0 : col_lo - 2;
+  const int g_hi = col_hi + 2 > gn ? gn : col_hi + 2;
+  const int nx = g_hi - g_lo;
+  size_t ncells = (size_t)nx * gn * gn + 1;  // + trash cell
   if (ncells > c->cell_capacity)
-    return fail(SPH_ERR_CAPACITY, "grid of %d^3 cells exceeds the context's capacity of %zu cells", gn,
-                c->cell_capacity);
-  derive(p, gn, 0, gn, &c->dev);
+    return fail(SPH_ERR_CAPACITY, "local grid of %d x %d x %d cells exceeds the context's capacity of %zu cells", nx,
+                gn, gn, c->cell_capacity);
+  derive(p, nx, g_lo, gn, &c->dev);
+  c->dev.own_lo = col_lo - g_lo;
+  c->dev.own_hi = col_hi - g_lo;
+  c->dev.dens_lo = c->dev.own_lo > 0 ? c->dev.own_lo - 1 : 0;
+  c->dev.dens_hi = c->dev.own_hi < nx ? c->dev.own_hi + 1 : nx;
   c->grid.ncells = ncells;
   c->grid.scan_blocks = (ncells + kScanItems - 1) / kScanItems;
   c->params = *p;
+  c->gn = gn;
+  c->col_lo = col_lo;
+  c->col_hi = col_hi;
+  return SPH_OK;
+}
+
+// Slab mode: the number of particles a step keeps is only known on the device; fetch it when needed.
+int resolve_n(sph_context* c) {
+  if (!c->n_pending) return SPH_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n = c->h_counters[2];
+  c->n_last_own = c->n;
+  c->lost += c->h_counters[3];
+  c->n_pending = false;
   return SPH_OK;
 }
 
 int one_step(sph_context* c) {
   const bool exact = (c->params.flags & SPH_FLAG_EXACT_ORDER) != 0;
   const bool keep = (c->params.flags & SPH_FLAG_KEEP_DEBUG) != 0;
+  int rc = resolve_n(c);
+  if (rc) return rc;
   const int n = c->n;
   { Timed t(c, CAT_HASH); launch_hash(c->stream, c->dev, c->cur, n, c->grid); }
   { Timed t(c, CAT_SCAN); launch_scan(c->stream, c->grid); }
   { Timed t(c, CAT_REORDER); launch_reorder(c->stream, c->cur, c->sorted, n, c->grid); }
   { Timed t(c, CAT_DENSITY);
     launch_density(c->stream, c->dev, c->sorted, n, c->grid, c->rho, keep ? c->dbg.ncount : nullptr, exact); }
+  State out = c->cur;
+  if (!c->slab) out.id = nullptr;  // same particles, same order: the id array is swapped below instead
   { Timed t(c, CAT_FORCE);
-    launch_force(c->stream, c->dev, c->sorted, c->cur, n, c->grid, c->rho, keep ? c->dbg.force : nullptr, exact); }
-  // cur now holds the new state in this step's sorted order; its ids are the sorted ids.
-  int32_t* t = c->cur.id;
-  c->cur.id = c->sorted.id;
-  c->sorted.id = t;
+    launch_force(c->stream, c->dev, c->sorted, out, n, c->grid, c->rho, keep ? c->dbg.force : nullptr,
+                 c->slab ? c->d_counters + 2 : nullptr, exact); }
   HIP_TRY(hipGetLastError());
+  c->dbg_stride = n;
+  if (c->slab) {
+    // ghosts and emigrants drop out here: only own-column particles were written back
+    HIP_TRY(hipMemcpyAsync(c->h_counters + 2, c->d_counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+    c->n_pending = true;
+  } else {
+    int32_t* t = c->cur.id;
+    c->cur.id = c->sorted.id;
+    c->sorted.id = t;
+    c->n_last_own = n;
+  }
   c->stepped = true;
   c->acc_steps += 1;
   c->acc_particles += (uint64_t)n;
@@ -236,6 +287,70 @@ int one_step(sph_context* c) {
   return SPH_OK;
 }
 
+int create_common(const sph_params* params, int n_max, int device, bool slab, int col_lo, int col_hi,
+                  int cols_capacity, sph_context** out);
+
+}  // namespace
+
+namespace {
+int create_common(const sph_params* params, int n_max, int device, bool slab, int col_lo, int col_hi,
+                  int cols_capacity, sph_context** out) {
+  if (!out) return fail(SPH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (n_max < 1) return fail(SPH_ERR_INVALID, "n_max must be >= 1 (got %d)", n_max);
+  int gn = cells_per_axis(params);
+  if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
+  if (!slab) { col_lo = 0; col_hi = gn; cols_capacity = gn; }
+  if (cols_capacity < col_hi - col_lo) cols_capacity = col_hi - col_lo;
+  if (cols_capacity > gn) cols_capacity = gn;
+  int cap_cols = cols_capacity + 4 > gn ? gn : cols_capacity + 4;
+  size_t ncells = (size_t)cap_cols * gn * gn + 1;
+  if (ncells + 1 > (size_t)0x7fffffff) return fail(SPH_ERR_CAPACITY, "%zu cells overflow the 32-bit cell index", ncells);
+
+  int ndev = sph_device_count();
+  if (ndev <= 0) return fail(SPH_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+  if (device < 0 || device >= ndev) return fail(SPH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SPH_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+
+  sph_context* c = new sph_context();
+  c->device = device;
+  c->n_max = n_max;
+  c->slab = slab;
+  c->cols_capacity = cols_capacity;
+  c->cell_capacity = ncells;
+  auto bail = [&](int code) { sph_destroy(c); return code; };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
+  const size_t n = (size_t)n_max;
+  if ((rc = alloc_state(&c->cur, n)) || (rc = alloc_state(&c->sorted, n))) return bail(rc);
+  // scan kernels read/write whole 4096-cell tiles through int4: round the tables up to a tile
+  size_t padded = ((ncells + kScanItems - 1) / kScanItems) * kScanItems;
+  if ((rc = dev_alloc(&c->grid.count, padded)) || (rc = dev_alloc(&c->grid.start, padded + 4)) ||
+      (rc = dev_alloc(&c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(&c->grid.cell_of, n)) ||
+      (rc = dev_alloc(&c->grid.rank_of, n)) || (rc = dev_alloc(&c->grid.src_of, n)) ||
+      (rc = dev_alloc(&c->grid.id_prov, n)) || (rc = dev_alloc(&c->grid.cell_s, n)) ||
+      (rc = dev_alloc(&c->rho, n)) || (rc = dev_alloc(&c->dbg.force, 3 * n)) ||
+      (rc = dev_alloc(&c->dbg.ncount, n)) || (rc = dev_alloc(&c->stage_pos, 3 * n)) ||
+      (rc = dev_alloc(&c->stage_vel, 3 * n)) || (rc = dev_alloc((uint32_t**)&c->stage_dbg, 6 * n)) ||
+      (rc = dev_alloc(&c->d_counters, 8)) || (rc = dev_alloc(&c->d_colcounts, (size_t)cap_cols + 4)))
+    return bail(rc);
+  if (hipHostMalloc((void**)&c->h_counters, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+    return bail(fail(SPH_ERR_HIP, "hipHostMalloc failed"));
+  memset(c->h_counters, 0, 8 * sizeof(int32_t));
+  if (hipMemsetAsync(c->grid.count, 0, padded * sizeof(int32_t), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->d_counters, 0, 8 * sizeof(int32_t), c->stream) != hipSuccess)
+    return bail(fail(SPH_ERR_HIP, "hipMemsetAsync failed"));
+  if ((rc = set_grid(c, params, col_lo, col_hi))) return bail(rc);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(SPH_ERR_HIP, "stream sync failed"));
+  *out = c;
+  return SPH_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -269,50 +384,7 @@ int sph_device_count(void) {
 }
 
 int sph_create(const sph_params* params, int n_max, int device, sph_context** out) {
-  if (!out) return fail(SPH_ERR_INVALID, "out is NULL");
-  *out = nullptr;
-  int rc = check_params(params);
-  if (rc) return rc;
-  if (n_max < 1) return fail(SPH_ERR_INVALID, "n_max must be >= 1 (got %d)", n_max);
-  int ndev = sph_device_count();
-  if (ndev <= 0) return fail(SPH_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
-  if (device < 0 || device >= ndev) return fail(SPH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(SPH_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
-  HIP_TRY(hipSetDevice(device));
-
-  int gn = cells_per_axis(params);
-  if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
-  size_t ncells = (size_t)gn * gn * gn;
-  if (ncells + 1 > (size_t)0x7fffffff) return fail(SPH_ERR_CAPACITY, "%zu cells overflow the 32-bit cell index", ncells);
-
-  sph_context* c = new sph_context();
-  c->device = device;
-  c->n_max = n_max;
-  c->cell_capacity = ncells;
-  auto bail = [&](int code) { sph_destroy(c); return code; };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
-    return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
-  const size_t n = (size_t)n_max;
-  if ((rc = alloc_state(&c->cur, n)) || (rc = alloc_state(&c->sorted, n))) return bail(rc);
-  // scan kernels read/write whole 4096-cell tiles through int4: round the tables up to a tile
-  size_t padded = ((ncells + kScanItems - 1) / kScanItems) * kScanItems;
-  if ((rc = dev_alloc(&c->grid.count, padded)) || (rc = dev_alloc(&c->grid.start, padded + 4)) ||
-      (rc = dev_alloc(&c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(&c->grid.cell_of, n)) ||
-      (rc = dev_alloc(&c->grid.rank_of, n)) || (rc = dev_alloc(&c->grid.src_of, n)) ||
-      (rc = dev_alloc(&c->grid.id_prov, n)) || (rc = dev_alloc(&c->grid.cell_s, n)) ||
-      (rc = dev_alloc(&c->rho, n)) || (rc = dev_alloc(&c->dbg.force, 3 * n)) ||
-      (rc = dev_alloc(&c->dbg.ncount, n)) || (rc = dev_alloc(&c->stage_pos, 3 * n)) ||
-      (rc = dev_alloc(&c->stage_vel, 3 * n)) || (rc = dev_alloc((uint32_t**)&c->stage_dbg, 6 * n)))
-    return bail(rc);
-  if (hipMemsetAsync(c->grid.count, 0, padded * sizeof(int32_t), c->stream) != hipSuccess)
-    return bail(fail(SPH_ERR_HIP, "hipMemsetAsync failed"));
-  if ((rc = set_grid(c, params))) return bail(rc);
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(SPH_ERR_HIP, "stream sync failed"));
-  *out = c;
-  return SPH_OK;
+  return create_common(params, n_max, device, false, 0, 0, 0, out);
 }
 
 int sph_destroy(sph_context* c) {
@@ -328,7 +400,9 @@ int sph_destroy(sph_context* c) {
   (void)hipFree(c->grid.id_prov); (void)hipFree(c->grid.cell_s);
   (void)hipFree(c->rho); (void)hipFree(c->dbg.force); (void)hipFree(c->dbg.ncount);
   (void)hipFree(c->stage_pos); (void)hipFree(c->stage_vel); (void)hipFree(c->stage_dbg);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  (void)hipFree(c->d_counters); (void)hipFree(c->d_colcounts);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SPH_OK;
 }
@@ -337,7 +411,7 @@ int sph_set_params(sph_context* c, const sph_params* p) {
   if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
   int rc = check_params(p);
   if (rc) return rc;
-  return set_grid(c, p);
+  return set_grid(c, p, c->col_lo, c->col_hi);
 }
 
 int sph_get_params(const sph_context* c, sph_params* p) {
@@ -360,6 +434,7 @@ static int upload_common(sph_context* c, const float* pos, const float* vel, int
   HIP_TRY(hipGetLastError());
   if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(c->stream));  // caller may reuse its buffers
   c->n = n;
+  c->n_pending = false;
   c->uploaded = true;
   c->stepped = false;
   return SPH_OK;
@@ -394,6 +469,7 @@ int sph_sync(sph_context* c) {
 static int download_common(sph_context* c, float* pos, float* vel, hipMemcpyKind kind) {
   if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
   if (!c->uploaded) return fail(SPH_ERR_STATE, "download before upload");
+  if (c->slab) return fail(SPH_ERR_STATE, "slab contexts hold global ids: use sph_slab_download");
   HIP_TRY(hipSetDevice(c->device));
   const int n = c->n;
   if (n > 0 && (pos || vel)) {
@@ -419,6 +495,7 @@ int sph_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount
   if (!c->stepped) return fail(SPH_ERR_STATE, "sph_download_debug needs at least one step after the upload");
   if ((force || ncount) && !(c->params.flags & SPH_FLAG_KEEP_DEBUG))
     return fail(SPH_ERR_STATE, "force/ncount need SPH_FLAG_KEEP_DEBUG set before the step");
+  if (c->slab) return fail(SPH_ERR_STATE, "slab contexts hold global ids: use sph_slab_download_debug");
   HIP_TRY(hipSetDevice(c->device));
   const size_t n = (size_t)c->n;
   if (n == 0) return SPH_OK;
@@ -438,7 +515,11 @@ int sph_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount
   return SPH_OK;
 }
 
-int sph_num_particles(const sph_context* c) { return c ? c->n : 0; }
+int sph_num_particles(const sph_context* c) {
+  if (!c) return 0;
+  if (c->n_pending) (void)resolve_n(const_cast<sph_context*>(c));
+  return c->n;
+}
 
 int sph_grid_dims(const sph_context* c, int dims[3]) {
   if (!c || !dims) return fail(SPH_ERR_INVALID, "NULL argument");
@@ -478,6 +559,195 @@ int sph_reset_timings(sph_context* c) {
   for (double& v : c->acc_ms) v = 0.0;
   c->acc_steps = 0;
   c->acc_particles = 0;
+  return SPH_OK;
+}
+
+// ---- slab decomposition ------------------------------------------------------------------------------------------
+
+int sph_global_cells(const sph_params* p, int* cells) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!cells) return fail(SPH_ERR_INVALID, "NULL argument");
+  int gn = cells_per_axis(p);
+  if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
+  *cells = gn;
+  return SPH_OK;
+}
+
+int sph_slab_create(const sph_params* params, int n_max, int device, int col_lo, int col_hi, int cols_capacity,
+                    sph_context** out) {
+  return create_common(params, n_max, device, true, col_lo, col_hi, cols_capacity, out);
+}
+
+int sph_slab_set_columns(sph_context* c, int col_lo, int col_hi) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->slab) return fail(SPH_ERR_STATE, "not a slab context");
+  if (col_hi - col_lo > c->cols_capacity)
+    return fail(SPH_ERR_CAPACITY, "%d columns exceed cols_capacity = %d", col_hi - col_lo, c->cols_capacity);
+  return set_grid(c, &c->params, col_lo, col_hi);
+}
+
+int sph_slab_get_columns(const sph_context* c, int* col_lo, int* col_hi, int* global_cols) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (col_lo) *col_lo = c->col_lo;
+  if (col_hi) *col_hi = c->col_hi;
+  if (global_cols) *global_cols = c->gn;
+  return SPH_OK;
+}
+
+int sph_slab_upload(sph_context* c, const float* pos, const float* vel, const int32_t* ids, int n) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (n < 0 || n > c->n_max) return fail(SPH_ERR_CAPACITY, "n = %d outside 0..n_max = %d", n, c->n_max);
+  if (n > 0 && (!pos || !vel || !ids)) return fail(SPH_ERR_INVALID, "positions/velocities/ids pointer is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if (n > 0) {
+    int32_t* d_ids = (int32_t*)c->stage_dbg;
+    HIP_TRY(hipMemcpyAsync(c->stage_pos, pos, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->stage_vel, vel, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    launch_split_aos_ids(c->stream, c->stage_pos, c->stage_vel, d_ids, n, c->cur);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n = n;
+  c->n_pending = false;
+  c->uploaded = true;
+  c->stepped = false;
+  return SPH_OK;
+}
+
+int sph_slab_download(sph_context* c, float* pos, float* vel, int32_t* ids, int capacity, int* n_out) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->uploaded) return fail(SPH_ERR_STATE, "download before upload");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  const int n = c->n;
+  if (n_out) *n_out = n;
+  if (n > capacity) return fail(SPH_ERR_CAPACITY, "%d particles do not fit the caller's capacity %d", n, capacity);
+  if (n > 0) {
+    int32_t* d_ids = (int32_t*)c->stage_dbg;
+    launch_join_aos(c->stream, c->cur, n, pos ? c->stage_pos : nullptr, vel ? c->stage_vel : nullptr,
+                    ids ? d_ids : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (pos) HIP_TRY(hipMemcpyAsync(pos, c->stage_pos, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (vel) HIP_TRY(hipMemcpyAsync(vel, c->stage_vel, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (ids) HIP_TRY(hipMemcpyAsync(ids, d_ids, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SPH_OK;
+}
+
+int sph_slab_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount, int32_t* cell, int capacity) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->stepped) return fail(SPH_ERR_STATE, "sph_slab_download_debug needs at least one step after the upload");
+  if ((force || ncount) && !(c->params.flags & SPH_FLAG_KEEP_DEBUG))
+    return fail(SPH_ERR_STATE, "force/ncount need SPH_FLAG_KEEP_DEBUG set before the step");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  const size_t n = (size_t)c->n_last_own;
+  if ((int)n > capacity) return fail(SPH_ERR_CAPACITY, "%zu particles do not fit the caller's capacity %d", n, capacity);
+  if (n == 0) return SPH_OK;
+  float* d_rho = (float*)c->stage_dbg;
+  float* d_force = d_rho + n;
+  int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
+  int32_t* d_cell = d_ncount + n;
+  // the force plane stride is the launch size of the step that wrote it: recover it from the step's n
+  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->rho, c->dbg.force, c->dbg.ncount,
+                    c->grid.cell_s, rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
+                    cell ? d_cell : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (rho) HIP_TRY(hipMemcpyAsync(rho, d_rho, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (force) HIP_TRY(hipMemcpyAsync(force, d_force, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (ncount) HIP_TRY(hipMemcpyAsync(ncount, d_ncount, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (cell) HIP_TRY(hipMemcpyAsync(cell, d_cell, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SPH_OK;
+}
+
+int sph_slab_pack(sph_context* c, float* d_left, float* d_right, int capacity, int* n_left, int* n_right) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->slab) return fail(SPH_ERR_STATE, "not a slab context");
+  if (!c->uploaded) return fail(SPH_ERR_STATE, "sph_slab_pack before upload");
+  if (!n_left || !n_right || capacity < 0) return fail(SPH_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  const bool has_left = c->col_lo > 0 && d_left, has_right = c->col_hi < c->gn && d_right;
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
+  {
+    Timed t(c, CAT_OTHER);
+    launch_slab_pack(c->stream, c->dev, c->cur, c->n, c->col_lo, c->col_hi, has_left, has_right, d_left, d_right,
+                     capacity, c->d_counters);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *n_left = c->h_counters[0];
+  *n_right = c->h_counters[1];
+  if (*n_left > capacity || *n_right > capacity)
+    return fail(SPH_ERR_CAPACITY, "halo/migration records (%d left, %d right) exceed the buffer capacity %d", *n_left,
+                *n_right, capacity);
+  return SPH_OK;
+}
+
+int sph_slab_append(sph_context* c, const float* d_rec, int n_rec) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->slab) return fail(SPH_ERR_STATE, "not a slab context");
+  if (n_rec < 0 || (n_rec > 0 && !d_rec)) return fail(SPH_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  if (c->n + n_rec > c->n_max)
+    return fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", c->n, n_rec, c->n_max);
+  {
+    Timed t(c, CAT_OTHER);
+    launch_slab_append(c->stream, d_rec, n_rec, c->cur, c->n);
+  }
+  HIP_TRY(hipGetLastError());
+  c->n += n_rec;
+  c->uploaded = true;
+  return SPH_OK;
+}
+
+int sph_slab_column_counts(sph_context* c, int32_t* counts, int capacity, int* ncols) {
+  if (!c || !counts) return fail(SPH_ERR_INVALID, "NULL argument");
+  if (!c->stepped) return fail(SPH_ERR_STATE, "column counts come from the last step's sort: step first");
+  HIP_TRY(hipSetDevice(c->device));
+  const int own = c->col_hi - c->col_lo;
+  if (ncols) *ncols = own;
+  if (own > capacity) return fail(SPH_ERR_CAPACITY, "%d own columns do not fit the caller's capacity %d", own, capacity);
+  launch_column_counts(c->stream, c->grid.start, c->dev.nx, c->dev.ny * c->dev.nz, c->d_colcounts);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(counts, c->d_colcounts + c->dev.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SPH_OK;
+}
+
+int sph_slab_lost(sph_context* c, int64_t* lost) {
+  if (!c || !lost) return fail(SPH_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  *lost = c->lost;
+  return SPH_OK;
+}
+
+int sph_get_stream(sph_context* c, void** stream) {
+  if (!c || !stream) return fail(SPH_ERR_INVALID, "NULL argument");
+  *stream = (void*)c->stream;
+  return SPH_OK;
+}
+
+int sph_set_stream(sph_context* c, void* stream) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)stream;
+  c->own_stream = false;
   return SPH_OK;
 }
 

@@ -21,6 +21,8 @@ struct DevParams {
   int nx, ny, nz;            // cells per axis of the local grid
   int cx_off;                // global x-column of local column 0 (slab decomposition)
   int gnx;                   // global cells per axis (for clamping before the offset)
+  int own_lo, own_hi;        // local x-columns this context integrates: [own_lo, own_hi)
+  int dens_lo, dens_hi;      // local x-columns whose density is needed: own plus one ghost column per side
   int tension;               // surface-tension term on/off
 };
 
@@ -31,6 +33,7 @@ struct State {
 };
 
 struct GridBuffers {
+  // ncells counts the real cells PLUS one trailing trash cell for particles outside the local grid.
   int32_t* count;      // [ncells]   histogram, left zeroed by the scan
   int32_t* start;      // [ncells+1] exclusive prefix sum: cell c owns slots [start[c], start[c+1])
   int32_t* block_sums; // scan scratch
@@ -57,7 +60,16 @@ void launch_reorder(hipStream_t s, const State& in, const State& out, int n, Gri
 void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, const GridBuffers& g,
                     float* rho, int32_t* ncount, bool exact);
 void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
-                  const GridBuffers& g, const float* rho, float* force_dbg, bool exact);
+                  const GridBuffers& g, const float* rho, float* force_dbg, int32_t* n_own_out, bool exact);
+void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
+                      bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters);
+void launch_slab_append(hipStream_t s, const float* rec, int n_rec, const State& st, int at);
+void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, const int32_t* ids, int n, State st);
+void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids);
+void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
+void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
+                       const float* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       float* rho, float* force, int32_t* ncount, int32_t* cell);
 void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos);
 void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float* rho_s,
                          const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,

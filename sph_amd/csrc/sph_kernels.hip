@@ -27,10 +27,6 @@ __device__ inline int cell_coord(float x, float cell, int gn) {
   q = fminf(fmaxf(q, 0.0f), (float)(gn - 1));
   return (int)q;
 }
-__device__ inline int local_col(int cx_global, const DevParams& P) {
-  int c = cx_global - P.cx_off;
-  return c < 0 ? 0 : (c > P.nx - 1 ? P.nx - 1 : c);
-}
 
 // ---- smoothing kernels, reference compute.cpp:41-95 (callers guarantee r <= h) ---------------------
 __device__ inline float w_poly6(const DevParams& P, float r) {  // :61-71
@@ -111,10 +107,12 @@ __global__ void k_hash(DevParams P, State in, int n, int32_t* __restrict__ cell_
                        int32_t* __restrict__ rank_of, int32_t* __restrict__ count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int cx = local_col(cell_coord(in.x[i], P.cell, P.gnx), P);
+  // A particle whose x-column lies outside this context's local grid (possible only in slab mode) goes to
+  // the trash cell appended after the last real cell: it sorts behind everything and no pass visits it.
+  int cx = cell_coord(in.x[i], P.cell, P.gnx) - P.cx_off;
   int cy = cell_coord(in.y[i], P.cell, P.ny);
   int cz = cell_coord(in.z[i], P.cell, P.nz);
-  int c = (cz * P.ny + cy) * P.nx + cx;
+  int c = (cx < 0 || cx >= P.nx) ? P.nx * P.ny * P.nz : (cx * P.ny + cy) * P.nz + cz;
   cell_of[i] = c;
   rank_of[i] = atomicAdd(&count[c], 1);
 }
@@ -268,29 +266,31 @@ __global__ void k_reorder(int n, State in, State out, const int32_t* __restrict_
 }
 
 // ---- neighbour sweeps --------------------------------------------------------------------------------------
-// The 27-cell stencil of a particle is 9 rows of (up to) 3 x-adjacent cells; with x the fastest-varying
-// cell coordinate each row is ONE contiguous slot range.  Rows are visited dz-major, dy-minor.
+// Cells are linearised as c = (cx*ny + cy)*nz + cz: z varies fastest and x, the slab-decomposition axis,
+// slowest, so every x-column of cells is one contiguous slot range.  The 27-cell stencil of a particle is
+// 9 rows of (up to) 3 z-adjacent cells, and each row is ONE contiguous slot range.  Rows are visited
+// dx-major, dy-minor.
 struct Stencil {
   int b[9], e[9];
 };
 
 __device__ inline void stencil_ranges(const DevParams& P, const int32_t* __restrict__ start, int c, Stencil& st) {
-  int cx = c % P.nx;
-  int t = c / P.nx;
+  int cz = c % P.nz;
+  int t = c / P.nz;
   int cy = t % P.ny;
-  int cz = t / P.ny;
-  int x0 = cx > 0 ? cx - 1 : 0;
-  int x1 = cx < P.nx - 1 ? cx + 1 : P.nx - 1;
+  int cx = t / P.ny;
+  int z0 = cz > 0 ? cz - 1 : 0;
+  int z1 = cz < P.nz - 1 ? cz + 1 : P.nz - 1;
   int k = 0;
 #pragma unroll
-  for (int dz = -1; dz <= 1; dz++) {
+  for (int dx = -1; dx <= 1; dx++) {
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++, k++) {
-      int y = cy + dy, z = cz + dz;
-      bool ok = y >= 0 && y < P.ny && z >= 0 && z < P.nz;
-      int row = ok ? (z * P.ny + y) * P.nx : 0;
-      st.b[k] = ok ? start[row + x0] : 0;
-      st.e[k] = ok ? start[row + x1 + 1] : 0;
+      int x = cx + dx, y = cy + dy;
+      bool ok = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
+      int row = ok ? (x * P.ny + y) * P.nz : 0;
+      st.b[k] = ok ? start[row + z0] : 0;
+      st.e[k] = ok ? start[row + z1 + 1] : 0;
     }
   }
 }
@@ -302,8 +302,10 @@ template <bool EXACT>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, State st, int n, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s, float* __restrict__ rho,
                                                     int32_t* __restrict__ ncount) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+  // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
+  const int cpc = P.ny * P.nz;
+  int s = start[P.dens_lo * cpc] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= start[P.dens_hi * cpc]) return;
   float xi = st.x[s], yi = st.y[s], zi = st.z[s];
   Stencil sc;
   stencil_ranges(P, start, cell_s[s], sc);
@@ -386,9 +388,19 @@ template <bool EXACT>
 __global__ void __launch_bounds__(kBlock) k_force(DevParams P, State st, State out, int n,
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s,
-                                                  const float* __restrict__ rho, float* __restrict__ force_dbg) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+                                                  const float* __restrict__ rho, float* __restrict__ force_dbg,
+                                                  int32_t* __restrict__ n_own_out) {
+  // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
+  const int cpc = P.ny * P.nz;
+  const int base = start[P.own_lo * cpc], bound = start[P.own_hi * cpc];
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o == 0 && n_own_out) {
+    const int real = P.nx * cpc;
+    n_own_out[0] = bound - base;                    // particles this context keeps
+    n_own_out[1] = start[real + 1] - start[real];   // trash cell: particles outside the local grid
+  }
+  const int s = base + o;
+  if (s >= bound) return;
   float xi = st.x[s], yi = st.y[s], zi = st.z[s];
   float vxi = st.vx[s], vyi = st.vy[s], vzi = st.vz[s];
   float rho_i = rho[s];
@@ -450,9 +462,9 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, State st, State o
     fz += t * nz;
   }
   if (force_dbg) {
-    force_dbg[s] = fx;
-    force_dbg[(size_t)n + s] = fy;
-    force_dbg[2 * (size_t)n + s] = fz;
+    force_dbg[o] = fx;
+    force_dbg[(size_t)n + o] = fy;
+    force_dbg[2 * (size_t)n + o] = fz;
   }
   // symplectic Euler (:265-280)
   float scl = P.dt / rho_i;
@@ -469,12 +481,112 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, State st, State o
   if (yi > P.tank) { yi = P.tank; vyi = -1.0f * vyi; }
   if (zi < 0.0f) { zi = 0.0f; vzi = -1.0f * vzi; }
   if (zi > P.tank) { zi = P.tank; vzi = -1.0f * vzi; }
-  out.x[s] = xi;
-  out.y[s] = yi;
-  out.z[s] = zi;
-  out.vx[s] = vxi;
-  out.vy[s] = vyi;
-  out.vz[s] = vzi;
+  out.x[o] = xi;
+  out.y[o] = yi;
+  out.z[o] = zi;
+  out.vx[o] = vxi;
+  out.vy[o] = vyi;
+  out.vz[o] = vzi;
+  if (out.id) out.id[o] = st.id[s];
+}
+
+// ---- slab decomposition: halo/migration records ---------------------------------------------------------------
+// A record is 7 words: x, y, z, vx, vy, vz, id (id bit-cast).  Records travel between neighbouring slabs.
+constexpr int kRecWords = 7;
+
+// Every particle whose x-column is within two columns of (or beyond) a slab face is copied to the buffer
+// for the neighbour behind that face: it is either a migrant (new owner: the neighbour) or a ghost for it.
+__global__ void k_slab_pack(DevParams P, State st, int n, int col_lo, int col_hi, int has_left, int has_right,
+                            float* __restrict__ rec_left, float* __restrict__ rec_right, int cap,
+                            int32_t* __restrict__ counters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int g = cell_coord(st.x[i], P.cell, P.gnx);
+  bool to_left = has_left && g < col_lo + 2;
+  bool to_right = has_right && g >= col_hi - 2;
+  if (!to_left && !to_right) return;
+  float r[kRecWords] = {st.x[i], st.y[i], st.z[i], st.vx[i], st.vy[i], st.vz[i], __int_as_float(st.id[i])};
+  if (to_left) {
+    int k = atomicAdd(&counters[0], 1);
+    if (k < cap)
+      for (int w = 0; w < kRecWords; w++) rec_left[(size_t)k * kRecWords + w] = r[w];
+  }
+  if (to_right) {
+    int k = atomicAdd(&counters[1], 1);
+    if (k < cap)
+      for (int w = 0; w < kRecWords; w++) rec_right[(size_t)k * kRecWords + w] = r[w];
+  }
+}
+
+__global__ void k_slab_append(const float* __restrict__ rec, int n_rec, State st, int at) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_rec) return;
+  const float* r = rec + (size_t)k * kRecWords;
+  int i = at + k;
+  st.x[i] = r[0];
+  st.y[i] = r[1];
+  st.z[i] = r[2];
+  st.vx[i] = r[3];
+  st.vy[i] = r[4];
+  st.vz[i] = r[5];
+  st.id[i] = __float_as_int(r[6]);
+}
+
+__global__ void k_split_aos_ids(const float* __restrict__ pos, const float* __restrict__ vel,
+                                const int32_t* __restrict__ ids, int n, State st) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st.x[i] = pos[3 * i + 0];
+  st.y[i] = pos[3 * i + 1];
+  st.z[i] = pos[3 * i + 2];
+  st.vx[i] = vel[3 * i + 0];
+  st.vy[i] = vel[3 * i + 1];
+  st.vz[i] = vel[3 * i + 2];
+  st.id[i] = ids[i];
+}
+
+// SoA -> AoS in storage order (no id permutation), ids alongside.
+__global__ void k_join_aos(State st, int n, float* __restrict__ pos, float* __restrict__ vel,
+                           int32_t* __restrict__ ids) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (pos) {
+    pos[3 * i + 0] = st.x[i];
+    pos[3 * i + 1] = st.y[i];
+    pos[3 * i + 2] = st.z[i];
+  }
+  if (vel) {
+    vel[3 * i + 0] = st.vx[i];
+    vel[3 * i + 1] = st.vy[i];
+    vel[3 * i + 2] = st.vz[i];
+  }
+  if (ids) ids[i] = st.id[i];
+}
+
+// Intermediates of the last step for the own particles, in the order the new state was written
+// (index o <-> sorted slot base + o).
+__global__ void k_join_debug(DevParams P, const int32_t* __restrict__ start, int n_own, int n_stride,
+                             const float* __restrict__ rho_s, const float* __restrict__ force_o,
+                             const int32_t* __restrict__ ncount_s, const int32_t* __restrict__ cell_s,
+                             float* rho, float* force, int32_t* ncount, int32_t* cell) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_own) return;
+  int s = start[P.own_lo * P.ny * P.nz] + o;
+  if (rho) rho[o] = rho_s[s];
+  if (force) {
+    force[3 * o + 0] = force_o[o];
+    force[3 * o + 1] = force_o[(size_t)n_stride + o];
+    force[3 * o + 2] = force_o[2 * (size_t)n_stride + o];
+  }
+  if (ncount) ncount[o] = ncount_s[s];
+  if (cell) cell[o] = cell_s[s];
+}
+
+// Particles per local x-column, from the cell start table of the last sort.
+__global__ void k_column_counts(const int32_t* __restrict__ start, int nx, int cpc, int32_t* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nx) return;
+  out[c] = start[(size_t)(c + 1) * cpc] - start[(size_t)c * cpc];
 }
 
 }  // namespace
@@ -516,13 +628,47 @@ void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, c
 }
 
 void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
-                  const GridBuffers& g, const float* rho, float* force_dbg, bool exact) {
+                  const GridBuffers& g, const float* rho, float* force_dbg, int32_t* n_own_out, bool exact) {
   if (n <= 0) return;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (exact)
-    hipLaunchKernelGGL(k_force<true>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg);
+    hipLaunchKernelGGL(k_force<true>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg, n_own_out);
   else
-    hipLaunchKernelGGL(k_force<false>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg);
+    hipLaunchKernelGGL(k_force<false>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg, n_own_out);
+}
+
+void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
+                      bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_slab_pack, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, col_lo, col_hi,
+                     has_left ? 1 : 0, has_right ? 1 : 0, rec_left, rec_right, cap, counters);
+}
+
+void launch_slab_append(hipStream_t s, const float* rec, int n_rec, const State& st, int at) {
+  if (n_rec <= 0) return;
+  hipLaunchKernelGGL(k_slab_append, dim3(div_up(n_rec, kBlock)), dim3(kBlock), 0, s, rec, n_rec, st, at);
+}
+
+void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, const int32_t* ids, int n, State st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_split_aos_ids, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, pos, vel, ids, n, st);
+}
+
+void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_join_aos, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, st, n, pos, vel, ids);
+}
+
+void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
+                       const float* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       float* rho, float* force, int32_t* ncount, int32_t* cell) {
+  if (n_own <= 0) return;
+  hipLaunchKernelGGL(k_join_debug, dim3(div_up(n_own, kBlock)), dim3(kBlock), 0, s, P, start, n_own, n_stride,
+                     rho_s, force_o, ncount_s, cell_s, rho, force, ncount, cell);
+}
+
+void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out) {
+  hipLaunchKernelGGL(k_column_counts, dim3(div_up(nx, kBlock)), dim3(kBlock), 0, s, start, nx, cpc, out);
 }
 
 void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos) {

@@ -24,24 +24,47 @@ def random_block(n, tank_size=0.2154, seed=12345):
     return pos, vel
 
 
+def _splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays (counter-based: no sequential state)."""
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def jitter_uniform(index, seed, axis):
+    """Uniform [0,1) float64 that depends only on (particle index, seed, axis).
+
+    Counter-based, so any rank can generate any subset of a field and get the same particles.
+    """
+    with np.errstate(over="ignore"):
+        key = index.astype(np.uint64) * np.uint64(3) + np.uint64(axis) + np.uint64(seed) * np.uint64(0x100000001B3)
+        bits = _splitmix64(_splitmix64(key))
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
 def jittered_lattice(nx, ny, nz, spacing=REST_SPACING, jitter=0.1, origin=(0.0, 0.0, 0.0),
-                     seed=12345, chunk=1 << 22):
+                     seed=12345, x_range=None, chunk=1 << 22, return_ids=False):
     """nx*ny*nz block on a simple-cubic lattice, each coordinate jittered by +-jitter*spacing.
 
-    Particle (i,j,k) sits at origin + (i+0.5, j+0.5, k+0.5)*spacing + jitter, x fastest.
-    Generated in chunks so that 16M+ particle fields do not need float64 temporaries of full size.
+    Particle (i,j,k) has index (i*ny + j)*nz + k (x-planes are contiguous: x is the slab
+    axis) and sits at origin + (i+0.5, j+0.5, k+0.5)*spacing + jitter.  x_range=(i0, i1)
+    generates only the planes i0 <= i < i1, bit-identical to the same particles of the full
+    field.  Generated in chunks so that 16M+ particle fields need no full-size float64 copies.
     """
-    n = nx * ny * nz
+    i0, i1 = (0, nx) if x_range is None else x_range
+    first, n = i0 * ny * nz, (i1 - i0) * ny * nz
     pos = np.empty((n, 3), dtype=np.float32)
-    rng = np.random.default_rng(seed)
     o = np.asarray(origin, dtype=np.float64)
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
-        idx = np.arange(a, b, dtype=np.int64)
-        ijk = np.stack([idx % nx, (idx // nx) % ny, idx // (nx * ny)], axis=1).astype(np.float64)
-        jit = (rng.random((b - a, 3)) * 2.0 - 1.0) * (jitter * spacing)
-        pos[a:b] = (o + (ijk + 0.5) * spacing + jit).astype(np.float32)
+        idx = np.arange(first + a, first + b, dtype=np.int64)
+        ijk = np.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], axis=1).astype(np.float64)
+        jit = np.stack([jitter_uniform(idx, seed, ax) for ax in range(3)], axis=1) * 2.0 - 1.0
+        pos[a:b] = (o + (ijk + 0.5) * spacing + jit * (jitter * spacing)).astype(np.float32)
     vel = np.zeros((n, 3), dtype=np.float32)
+    if return_ids:
+        return pos, vel, np.arange(first, first + n, dtype=np.int32)
     return pos, vel
 
 
@@ -64,11 +87,14 @@ def uniform_cube(side, seed=12345, jitter=0.1):
     return pos, vel, params
 
 
-def dam_break_slab_x(side_x, side_yz, seed=12345, jitter=0.1):
-    """Dam-break block of side_x * side_yz^2 particles (x is the slab-decomposition axis)."""
-    params = default_params(tank_size=2.0 * max(side_x, side_yz) * REST_SPACING)
-    pos, vel = jittered_lattice(side_x, side_yz, side_yz, seed=seed, jitter=jitter)
-    return pos, vel, params
+def dam_break_params(side):
+    """Parameters of the side^3 dam break: reference defaults, tank twice the block's width."""
+    return default_params(tank_size=2.0 * side * REST_SPACING)
+
+
+def dam_break_planes(side, x_range, seed=12345, jitter=0.1):
+    """The lattice x-planes x_range=(i0, i1) of dam_break(side), with global particle ids."""
+    return jittered_lattice(side, side, side, seed=seed, jitter=jitter, x_range=x_range, return_ids=True)
 
 
 def wall_contact(n, tank_size=0.2154, seed=7):

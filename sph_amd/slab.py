@@ -1,0 +1,220 @@
+"""Slab domain decomposition along x: host-side orchestration of one rank per GPU.
+
+The reference is a single shared-memory process (OpenMP only, reference compute/compute.cpp:131-287);
+it has no distributed counterpart.  Interactions are strictly local (every kernel vanishes beyond
+r = h, compute.cpp:44,53,64,76,88), so the tank is cut into slabs on cell-column boundaries and each
+rank talks only to its two neighbours:
+
+    records_left, records_right = backend.pack()          # migrants + 2 ghost columns per face
+    from_left, from_right = exchange(records_left, records_right)
+    backend.append(from_left); backend.append(from_right)
+    backend.step()                                        # afterwards: own particles only
+
+The exchange is point-to-point (torch.distributed isend/irecv; backend "nccl" is RCCL over xGMI, each
+neighbour pair on its own direct link); no collective sits on the data path.  Load balancing moves
+the cut planes by at most one column per step towards equal particle counts, using a per-column
+histogram all-gathered every `rebalance_every` steps (a few KB, off the data path).
+
+This module contains no physics: `backend` is sph_amd.capi.SlabSimulation (HIP) in production.
+"""
+import numpy as np
+
+from .capi import MIN_SLAB_COLUMNS, RECORD_WORDS  # noqa: F401
+
+
+# ---- cut planes ---------------------------------------------------------------------------------------
+
+def partition_columns(hist, nranks, min_cols=MIN_SLAB_COLUMNS):
+    """Cut `len(hist)` columns into nranks contiguous slabs with near-equal particle counts.
+
+    Returns cuts[0..nranks] with cuts[0] = 0, cuts[-1] = len(hist); slab r owns columns
+    [cuts[r], cuts[r+1]).  Every slab gets at least min_cols columns.
+    """
+    hist = np.asarray(hist, dtype=np.int64)
+    ncols = hist.size
+    if nranks * min_cols > ncols:
+        raise ValueError(f"{ncols} columns cannot hold {nranks} slabs of >= {min_cols} columns")
+    csum = np.concatenate([[0], np.cumsum(hist)])
+    total = csum[-1]
+    cuts = [0]
+    for r in range(1, nranks):
+        target = total * r / nranks
+        c = int(np.searchsorted(csum, target, side="left"))
+        # pick the boundary whose cumulative count is closest to the target
+        if c > 0 and abs(csum[c - 1] - target) <= abs(csum[min(c, ncols)] - target):
+            c -= 1
+        lo = cuts[-1] + min_cols
+        hi = ncols - (nranks - r) * min_cols
+        cuts.append(int(min(max(c, lo), hi)))
+    cuts.append(ncols)
+    return cuts
+
+
+def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
+    """Move every interior cut by at most max_shift columns towards the balanced partition."""
+    nranks = len(cuts) - 1
+    ideal = partition_columns(hist, nranks, min_cols)
+    new = list(cuts)
+    for r in range(1, nranks):
+        step = int(np.clip(ideal[r] - cuts[r], -max_shift, max_shift))
+        new[r] = cuts[r] + step
+    # keep the minimum width after the individual moves
+    for r in range(1, nranks):
+        new[r] = max(new[r], new[r - 1] + min_cols)
+    for r in range(nranks - 1, 0, -1):
+        new[r] = min(new[r], new[r + 1] - min_cols)
+    return new
+
+
+# ---- exchanges --------------------------------------------------------------------------------------------
+
+class LocalExchange:
+    """All slabs live in one process (tests; several slabs on one GPU): hand the buffers over directly."""
+
+    def __init__(self, nranks):
+        self.nranks = nranks
+        self.outbox = [None] * nranks
+
+    def post(self, rank, left, right):
+        self.outbox[rank] = (left, right)
+
+    def collect(self, rank):
+        from_left = self.outbox[rank - 1][1] if rank > 0 else None
+        from_right = self.outbox[rank + 1][0] if rank < self.nranks - 1 else None
+        return from_left, from_right
+
+
+class DistExchange:
+    """Neighbour exchange over torch.distributed point-to-point operations.
+
+    With the "nccl" backend (RCCL on ROCm) the record tensors stay in HBM and travel over xGMI;
+    with "gloo" they are staged through host memory (CPU tests, single-GPU rehearsals).
+    """
+
+    def __init__(self, rank, nranks, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.nranks, self.group = rank, nranks, group
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.device = device if self.on_device else torch.device("cpu")
+        self.data_device = device if device is not None else torch.device("cpu")
+        self.bytes_sent = 0
+
+    def _neighbours(self):
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.nranks - 1 else None
+        return left, right
+
+    def exchange(self, send_left, send_right):
+        torch, dist = self.torch, self.dist
+        left, right = self._neighbours()
+        # 1. counts (two ints per neighbour)
+        counts_out = torch.tensor([send_left.shape[0] if left is not None else 0,
+                                   send_right.shape[0] if right is not None else 0],
+                                  dtype=torch.int64, device=self.device)
+        from_left_n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        from_right_n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ops = []
+        if left is not None:
+            ops.append(dist.P2POp(dist.isend, counts_out[0:1], left, self.group))
+            ops.append(dist.P2POp(dist.irecv, from_left_n, left, self.group))
+        if right is not None:
+            ops.append(dist.P2POp(dist.isend, counts_out[1:2], right, self.group))
+            ops.append(dist.P2POp(dist.irecv, from_right_n, right, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        nl, nr = int(from_left_n.item()), int(from_right_n.item())
+        # 2. payload, exact sizes
+        recv_left = torch.empty((nl, RECORD_WORDS), dtype=torch.float32, device=self.device)
+        recv_right = torch.empty((nr, RECORD_WORDS), dtype=torch.float32, device=self.device)
+        ops = []
+        if left is not None:
+            if send_left.shape[0]:
+                ops.append(dist.P2POp(dist.isend, self._out(send_left), left, self.group))
+            if nl:
+                ops.append(dist.P2POp(dist.irecv, recv_left, left, self.group))
+        if right is not None:
+            if send_right.shape[0]:
+                ops.append(dist.P2POp(dist.isend, self._out(send_right), right, self.group))
+            if nr:
+                ops.append(dist.P2POp(dist.irecv, recv_right, right, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.bytes_sent += 4 * RECORD_WORDS * (send_left.shape[0] + send_right.shape[0])
+        return self._in(recv_left), self._in(recv_right)
+
+    def _out(self, t):
+        return t.contiguous() if self.on_device else t.detach().to("cpu").contiguous()
+
+    def _in(self, t):
+        return t if t.device == self.data_device else t.to(self.data_device)
+
+    def allgather_histogram(self, local_hist, cuts, ncols):
+        """Global per-column particle histogram from every rank's own-column counts."""
+        torch, dist = self.torch, self.dist
+        full = torch.zeros(ncols, dtype=torch.int64, device=self.device)
+        lo = cuts[self.rank]
+        full[lo:lo + len(local_hist)] = torch.as_tensor(np.asarray(local_hist, dtype=np.int64), device=self.device)
+        dist.all_reduce(full, group=self.group)
+        return full.cpu().numpy()
+
+
+# ---- per-rank driver ----------------------------------------------------------------------------------------
+
+class SlabRunner:
+    """Drives one slab.  `backend` supplies pack / append / step / column_counts / set_columns."""
+
+    def __init__(self, backend, exchange, rank, nranks, cuts, rebalance_every=0):
+        self.backend, self.exchange = backend, exchange
+        self.rank, self.nranks = rank, nranks
+        self.cuts = list(cuts)
+        self.rebalance_every = rebalance_every
+        self.steps_done = 0
+
+    def step(self):
+        b = self.backend
+        send_left, send_right = b.pack()
+        from_left, from_right = self.exchange.exchange(send_left, send_right)
+        b.append(from_left)
+        b.append(from_right)
+        b.step()
+        self.steps_done += 1
+        if self.rebalance_every and self.steps_done % self.rebalance_every == 0 and self.nranks > 1:
+            self.rebalance()
+
+    def rebalance(self):
+        b = self.backend
+        hist = self.exchange.allgather_histogram(b.column_counts(), self.cuts, self.cuts[-1])
+        new = rebalance_cuts(self.cuts, hist)
+        if new != self.cuts:
+            self.cuts = new
+            b.set_columns(new[self.rank], new[self.rank + 1])
+
+
+def step_local_slabs(backends, exchange):
+    """One step of several slabs that live in ONE process (LocalExchange)."""
+    for r, b in enumerate(backends):
+        left, right = b.pack()
+        exchange.post(r, left, right)
+    for r, b in enumerate(backends):
+        from_left, from_right = exchange.collect(r)
+        b.append(from_left)
+        b.append(from_right)
+    for b in backends:
+        b.step()
+
+
+def rebalance_local_slabs(backends, cuts):
+    """Rebalancing counterpart of step_local_slabs: returns the new cuts and applies them."""
+    hist = np.zeros(cuts[-1], np.int64)
+    for r, b in enumerate(backends):
+        c = b.column_counts()
+        hist[cuts[r]:cuts[r] + len(c)] = c
+    new = rebalance_cuts(cuts, hist)
+    if new != list(cuts):
+        for r, b in enumerate(backends):
+            b.set_columns(new[r], new[r + 1])
+    return new

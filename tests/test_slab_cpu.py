@@ -1,0 +1,110 @@
+"""CPU tests of the multi-rank path: cut planes, record routing, ownership, rebalancing and the
+torch.distributed exchange (gloo, world_size 2), with the CPU grid twin standing in for the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits_equal
+
+from sph_amd import scenes, slab
+from sph_amd.params import default_params
+from slab_backends import OracleSlabBackend
+
+
+def moving_block(n_side=12, seed=3, speed=0.8):
+    """Jittered block in the middle of the default tank with velocities up to ~speed m/s in x:
+    0.8 m/s * 0.005 s = 0.4 cell per step, so particles migrate across cut planes within a few steps."""
+    pos, vel, ids = scenes.jittered_lattice(n_side, n_side, n_side, origin=(0.06, 0.05, 0.05), seed=seed,
+                                            return_ids=True)
+    rng = np.random.default_rng(seed)
+    vel = ((rng.random(vel.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(2 * speed)).astype(np.float32)
+    return pos, vel, ids
+
+
+def by_id(pos, vel, ids):
+    o = np.argsort(ids)
+    return pos[o], vel[o], ids[o]
+
+
+# ---- cut planes ----------------------------------------------------------------------------------------
+
+def test_partition_balances_and_respects_min_width():
+    hist = np.zeros(140, np.int64)
+    hist[:70] = 14286  # dam break: half the tank is empty
+    cuts = slab.partition_columns(hist, 8)
+    assert cuts[0] == 0 and cuts[-1] == 140 and len(cuts) == 9
+    widths = np.diff(cuts)
+    assert widths.min() >= slab.MIN_SLAB_COLUMNS
+    loads = [hist[cuts[r]:cuts[r + 1]].sum() for r in range(8)]
+    assert max(loads) <= 1.2 * hist.sum() / 8
+    with pytest.raises(ValueError):
+        slab.partition_columns(np.ones(10), 4)
+
+
+def test_partition_with_empty_histogram_still_valid():
+    cuts = slab.partition_columns(np.zeros(40, np.int64), 4)
+    assert np.diff(cuts).min() >= slab.MIN_SLAB_COLUMNS and cuts[-1] == 40
+
+
+def test_rebalance_moves_one_column_at_a_time():
+    hist = np.zeros(60, np.int64)
+    hist[:20] = 100
+    cuts = [0, 30, 60]
+    seen = [cuts]
+    for _ in range(30):
+        cuts = slab.rebalance_cuts(cuts, hist)
+        assert abs(cuts[1] - seen[-1][1]) <= 1
+        seen.append(cuts)
+    assert cuts[1] == 10  # converged to the balanced cut
+
+
+# ---- several slabs in one process -------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nslabs,rebalance", [(2, False), (3, False), (3, True)])
+def test_local_slabs_match_single_domain_bitwise(oracle, nslabs, rebalance):
+    p = default_params()
+    pos, vel, ids = moving_block()
+    gn = oracle.consts(p).ncell
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    cuts = slab.partition_columns(np.bincount(cols, minlength=gn), nslabs)
+    backends = []
+    for r in range(nslabs):
+        b = OracleSlabBackend(oracle, p, cuts[r], cuts[r + 1])
+        m = (cols >= cuts[r]) & (cols < cuts[r + 1])
+        b.upload(pos[m], vel[m], ids[m])
+        backends.append(b)
+    ex = slab.LocalExchange(nslabs)
+    rp, rv = pos.copy(), vel.copy()
+    migrated = 0
+    owner_before = np.searchsorted(cuts, cols, side="right") - 1
+    for s in range(8):
+        slab.step_local_slabs(backends, ex)
+        if rebalance:
+            cuts = slab.rebalance_local_slabs(backends, cuts)
+        oracle.step_grid(p, rp, rv, ids, order=0)
+        assert sum(b.n for b in backends) == ids.size, "particles lost or duplicated"
+    got = by_id(*[np.concatenate(x) for x in zip(*[b.download() for b in backends])])
+    assert np.array_equal(got[2], ids)
+    assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
+    owner_after = np.empty(ids.size, np.int64)
+    for r, b in enumerate(backends):
+        owner_after[b.download()[2]] = r
+    migrated = int((owner_after != owner_before).sum())
+    assert migrated > 0, "the scene must exercise migration across cut planes"
+
+
+# ---- torch.distributed, gloo, world_size 2 -------------------------------------------------------------------
+
+def test_gloo_two_ranks_match_single_domain(tmp_path):
+    script = os.path.join(ROOT, "tests", "slab_gloo_worker.py")
+    port = 29500 + (os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, script, str(tmp_path)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [pr.communicate(timeout=240)[0] for pr in procs]
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r} failed:\n{outs[r]}"
+    assert "BITWISE_MATCH" in outs[0], outs[0]
