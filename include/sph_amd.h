@@ -48,7 +48,10 @@ enum {
   SPH_FLAG_EXACT_ORDER = 1u << 1,
   /* Keep per-particle total force density and neighbour counts of the last step for
    * sph_download_debug (costs 16 B/particle of extra stores per step). */
-  SPH_FLAG_KEEP_DEBUG = 1u << 2
+  SPH_FLAG_KEEP_DEBUG = 1u << 2,
+  /* Ablation switch for the density and force passes; results are the same bit for bit.
+   * LANE_SWEEP: plain one-lane-per-particle sweep without neighbour queues. */
+  SPH_FLAG_LANE_SWEEP = 1u << 3
 };
 
 /*

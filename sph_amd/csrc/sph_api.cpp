@@ -46,10 +46,11 @@ struct sph_context {
   sph_params params{};
   DevParams dev{};
   int n_max = 0, n = 0;
-  State cur{}, sorted{};  // cur: state the next step starts from; sorted: this step's grid-ordered copy
+  State cur{};      // SoA state the next step starts from (sorted order of the previous step)
+  Sorted sorted{};  // this step's grid-ordered, gather-packed copy
+  NeighbourMask nmask{};
   GridBuffers grid{};
   size_t cell_capacity = 0;
-  float* rho = nullptr;
   DebugBuffers dbg{};
   float *stage_pos = nullptr, *stage_vel = nullptr;  // AoS staging in HBM, 3*n_max floats each
   void* stage_dbg = nullptr;                         // 6*n_max words for debug downloads
@@ -260,13 +261,16 @@ int one_step(sph_context* c) {
   { Timed t(c, CAT_HASH); launch_hash(c->stream, c->dev, c->cur, n, c->grid); }
   { Timed t(c, CAT_SCAN); launch_scan(c->stream, c->grid); }
   { Timed t(c, CAT_REORDER); launch_reorder(c->stream, c->cur, c->sorted, n, c->grid); }
+  SweepMode mode = SWEEP_QUEUED;
+  if (exact) mode = SWEEP_EXACT;
+  else if (c->params.flags & SPH_FLAG_LANE_SWEEP) mode = SWEEP_PLAIN;
   { Timed t(c, CAT_DENSITY);
-    launch_density(c->stream, c->dev, c->sorted, n, c->grid, c->rho, keep ? c->dbg.ncount : nullptr, exact); }
+    launch_density(c->stream, c->dev, c->sorted, n, c->grid, keep ? c->dbg.ncount : nullptr, c->nmask, mode); }
   State out = c->cur;
   if (!c->slab) out.id = nullptr;  // same particles, same order: the id array is swapped below instead
   { Timed t(c, CAT_FORCE);
-    launch_force(c->stream, c->dev, c->sorted, out, n, c->grid, c->rho, keep ? c->dbg.force : nullptr,
-                 c->slab ? c->d_counters + 2 : nullptr, exact); }
+    launch_force(c->stream, c->dev, c->sorted, out, n, c->grid, keep ? c->dbg.force : nullptr,
+                 c->slab ? c->d_counters + 2 : nullptr, c->nmask, mode); }
   HIP_TRY(hipGetLastError());
   c->dbg_stride = n;
   if (c->slab) {
@@ -328,14 +332,18 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
   const size_t n = (size_t)n_max;
-  if ((rc = alloc_state(&c->cur, n)) || (rc = alloc_state(&c->sorted, n))) return bail(rc);
+  if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n)) || (rc = dev_alloc(&c->sorted.vel, n)) ||
+      (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)kMaskWords * n)) ||
+      (rc = dev_alloc(&c->nmask.ncand, n)))
+    return bail(rc);
+  c->nmask.stride = n;
   // scan kernels read/write whole 4096-cell tiles through int4: round the tables up to a tile
   size_t padded = ((ncells + kScanItems - 1) / kScanItems) * kScanItems;
   if ((rc = dev_alloc(&c->grid.count, padded)) || (rc = dev_alloc(&c->grid.start, padded + 4)) ||
       (rc = dev_alloc(&c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(&c->grid.cell_of, n)) ||
       (rc = dev_alloc(&c->grid.rank_of, n)) || (rc = dev_alloc(&c->grid.src_of, n)) ||
       (rc = dev_alloc(&c->grid.id_prov, n)) || (rc = dev_alloc(&c->grid.cell_s, n)) ||
-      (rc = dev_alloc(&c->rho, n)) || (rc = dev_alloc(&c->dbg.force, 3 * n)) ||
+      (rc = dev_alloc(&c->dbg.force, 3 * n)) ||
       (rc = dev_alloc(&c->dbg.ncount, n)) || (rc = dev_alloc(&c->stage_pos, 3 * n)) ||
       (rc = dev_alloc(&c->stage_vel, 3 * n)) || (rc = dev_alloc((uint32_t**)&c->stage_dbg, 6 * n)) ||
       (rc = dev_alloc(&c->d_counters, 8)) || (rc = dev_alloc(&c->d_colcounts, (size_t)cap_cols + 4)))
@@ -394,11 +402,12 @@ int sph_destroy(sph_context* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   free_state(&c->cur);
-  free_state(&c->sorted);
+  (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.vel); (void)hipFree(c->sorted.id);
+  (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand);
   (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.block_sums);
   (void)hipFree(c->grid.cell_of); (void)hipFree(c->grid.rank_of); (void)hipFree(c->grid.src_of);
   (void)hipFree(c->grid.id_prov); (void)hipFree(c->grid.cell_s);
-  (void)hipFree(c->rho); (void)hipFree(c->dbg.force); (void)hipFree(c->dbg.ncount);
+  (void)hipFree(c->dbg.force); (void)hipFree(c->dbg.ncount);
   (void)hipFree(c->stage_pos); (void)hipFree(c->stage_vel); (void)hipFree(c->stage_dbg);
   (void)hipFree(c->d_counters); (void)hipFree(c->d_colcounts);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -503,7 +512,7 @@ int sph_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount
   float* d_force = d_rho + n;
   int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
   int32_t* d_cell = d_ncount + n;
-  launch_gather_debug(c->stream, c->cur.id, (int)n, c->rho, c->dbg.force, c->dbg.ncount, c->grid.cell_s,
+  launch_gather_debug(c->stream, c->cur.id, (int)n, c->sorted.vel, c->dbg.force, c->dbg.ncount, c->grid.cell_s,
                       rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
                       cell ? d_cell : nullptr);
   HIP_TRY(hipGetLastError());
@@ -654,7 +663,7 @@ int sph_slab_download_debug(sph_context* c, float* rho, float* force, int32_t* n
   int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
   int32_t* d_cell = d_ncount + n;
   // the force plane stride is the launch size of the step that wrote it: recover it from the step's n
-  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->rho, c->dbg.force, c->dbg.ncount,
+  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->sorted.vel, c->dbg.force, c->dbg.ncount,
                     c->grid.cell_s, rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
                     cell ? d_cell : nullptr);
   HIP_TRY(hipGetLastError());

@@ -1,0 +1,134 @@
+// Device-side arithmetic shared by every neighbour sweep.  All of it mirrors the reference expression by
+// expression (reference compute/compute.cpp, lines cited inline); translation units that include this
+// header must be compiled with -ffp-contract=off.
+#pragma once
+
+#include "sph_internal.hpp"
+
+namespace sph {
+
+// ---- cell index ---------------------------------------------------------------------------------
+// c = clamp(floorf(x / cell), 0, gn-1).  True fp32 division: x * (1/cell) rounds differently.
+// fmaxf(NaN, 0) = 0 keeps NaN positions inside the table.
+__device__ inline int cell_coord(float x, float cell, int gn) {
+  float q = floorf(x / cell);
+  q = fminf(fmaxf(q, 0.0f), (float)(gn - 1));
+  return (int)q;
+}
+
+__device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
+
+// ---- smoothing kernels, compute.cpp:41-95 (callers guarantee r <= h) -------------------------------
+__device__ inline float w_poly6(const DevParams& P, float r) {  // :61-71
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d3 = d * d * d;
+  return (float)(P.c_poly6 * (double)d3);
+}
+__device__ inline float grad_spiky(const DevParams& P, float r) {  // :50-59
+  float d = P.h - r;
+  float d2 = d * d;
+  return (float)(P.c_spiky_grad * (double)d2);
+}
+__device__ inline float lapl_visc(const DevParams& P, float r) {  // :41-48
+  return (float)(P.c_visc_lapl * (double)(P.h - r));
+}
+__device__ inline float grad_poly6(const DevParams& P, float r) {  // :73-83
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d2 = d * d;
+  return (float)(P.c_poly6_grad * (double)r * (double)d2);
+}
+__device__ inline float lapl_poly6(const DevParams& P, float r) {  // :85-95
+  float rr = r * r;
+  float d = P.h2 - rr;
+  float d2 = d * d;
+  float poly = 4.0f * rr * d - d2;
+  return (float)(P.c_poly6_lapl * (double)poly);
+}
+
+// ---- one neighbour's contribution to the three pair sums (:161-179, :194-209, :233-253) -------------
+constexpr int kForceComps = 10;
+struct PairOut {
+  float v[kForceComps];  // 0-2 pressure (:176-178)  3-5 viscosity (:206-208)  6-8 colour gradient (:248-250)  9 colour laplacian (:252)
+};
+
+__device__ inline PairOut pair_eval(const DevParams& P, float dx, float dy, float dz, float r2, float pi,
+                                    float rho_j, float dvx, float dvy, float dvz) {
+  PairOut o;
+  float r = sqrtf(r2);
+  float ux = 0.0f, uy = 0.0f, uz = 0.0f;  // vecNormalize(r, r)  :28-39
+  if (r > 0.0f) {
+    ux = dx / r;
+    uy = dy / r;
+    uz = dz / r;
+  }
+  float pj = P.c2 * (rho_j - P.rho0);                                    // :164
+  float mfp = P.neg_m * (pi + pj) / (2.0f * rho_j) * grad_spiky(P, r);  // :170
+  o.v[0] = mfp * ux;
+  o.v[1] = mfp * uy;
+  o.v[2] = mfp * uz;
+  float t = P.visc_m * lapl_visc(P, r) / rho_j;  // :204
+  o.v[3] = dvx * t;
+  o.v[4] = dvy * t;
+  o.v[5] = dvz * t;
+  if (P.tension) {
+    float mg = P.m * grad_poly6(P, r) / rho_j;  // :242
+    o.v[6] = ux * mg;
+    o.v[7] = uy * mg;
+    o.v[8] = uz * mg;
+    o.v[9] = P.m * lapl_poly6(P, r) / rho_j;  // :252
+  } else {
+    o.v[6] = o.v[7] = o.v[8] = o.v[9] = 0.0f;
+  }
+  return o;
+}
+
+// ---- per-particle epilogue: total force, symplectic Euler, tank walls --------------------------------
+struct Advanced {
+  float x, y, z, vx, vy, vz, fx, fy, fz;
+};
+
+// a[] holds the ten sums in PairOut order.
+__device__ inline Advanced finish_particle(const DevParams& P, const float* a, float xi, float yi, float zi,
+                                           float vxi, float vyi, float vzi, float rho_i) {
+  // f_total = (((0 + pressure) + viscosity) + gravity*rho) + tension   (:181-183,:211-213,:220-222,:259-261)
+  float fx = 0.0f + a[0], fy = 0.0f + a[1], fz = 0.0f + a[2];
+  fx += a[3];
+  fy += a[4];
+  fz += a[5];
+  fx += P.gx * rho_i;
+  fy += P.gy * rho_i;
+  fz += P.gz * rho_i;
+  if (P.tension) {
+    float len = sqrtf(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);  // vecNormalize(gradcolor)  :255
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    if (len > 0.0f) {
+      nx = a[6] / len;
+      ny = a[7] / len;
+      nz = a[8] / len;
+    }
+    float t = P.neg_sigma * a[9];  // :257
+    fx += t * nx;
+    fy += t * ny;
+    fz += t * nz;
+  }
+  // symplectic Euler (:265-280)
+  float scl = P.dt / rho_i;
+  vxi += fx * scl;
+  vyi += fy * scl;
+  vzi += fz * scl;
+  xi = xi + vxi * P.dt;
+  yi = yi + vyi * P.dt;
+  zi = zi + vzi * P.dt;
+  // tank walls, damping 1 (:286-319)
+  if (xi < 0.0f) { xi = 0.0f; vxi = -1.0f * vxi; }
+  if (xi > P.tank) { xi = P.tank; vxi = -1.0f * vxi; }
+  if (yi < 0.0f) { yi = 0.0f; vyi = -1.0f * vyi; }
+  if (yi > P.tank) { yi = P.tank; vyi = -1.0f * vyi; }
+  if (zi < 0.0f) { zi = 0.0f; vzi = -1.0f * vzi; }
+  if (zi > P.tank) { zi = P.tank; vzi = -1.0f * vzi; }
+  return Advanced{xi, yi, zi, vxi, vyi, vzi, fx, fy, fz};
+}
+
+}  // namespace sph

@@ -1,0 +1,173 @@
+// sph_headless: the reference's main loop (main.cpp:22-44) without OpenGL.
+//
+//   initOpenGL/initGeometry        -> nothing
+//   initParticles                  -> the drop-in shim's initParticles (or a dam-break block)
+//   while (!closeWindow) { updateParticles; display }
+//                                  -> a fixed number of steps; `display` becomes a periodic dump of the
+//                                     particle state (the hand-off a viewer or a checkpoint reader consumes)
+//
+// Two modes:
+//   --mode shim      every step goes through updateParticles() on host arrays, exactly like main.cpp:33
+//                    (host arrays valid after every call, as display() expects, render.cpp:240-253)
+//   --mode resident  state stays in HBM between steps (sph_upload once, sph_step, sph_download at dumps)
+//
+// Dump file: 64-byte header {magic "SPHD", u32 version=1, u32 n, u32 step, sph_params (52 bytes)}, then
+// float32 pos[3n], float32 vel[3n].  A dump is also a checkpoint: --resume FILE continues from it.
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sph_amd.h"
+#include "../../include/sph_compute_shim.h"
+
+namespace {
+
+struct DumpHeader {
+  char magic[4];
+  uint32_t version, n, step;
+  sph_params params;
+};
+static_assert(sizeof(DumpHeader) == 16 + sizeof(sph_params), "dump header layout");
+
+bool write_dump(const std::string& path, const sph_params& p, uint32_t step, const std::vector<float>& pos,
+                const std::vector<float>& vel) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  DumpHeader hd{{'S', 'P', 'H', 'D'}, 1u, (uint32_t)(pos.size() / 3), step, p};
+  bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(pos.data(), sizeof(float), pos.size(), f) == pos.size() &&
+            std::fwrite(vel.data(), sizeof(float), vel.size(), f) == vel.size();
+  std::fclose(f);
+  return ok;
+}
+
+bool read_dump(const std::string& path, sph_params* p, uint32_t* step, std::vector<float>* pos, std::vector<float>* vel) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  DumpHeader hd;
+  bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, "SPHD", 4) == 0 && hd.version == 1;
+  if (ok) {
+    pos->resize((size_t)hd.n * 3);
+    vel->resize((size_t)hd.n * 3);
+    ok = std::fread(pos->data(), sizeof(float), pos->size(), f) == pos->size() &&
+         std::fread(vel->data(), sizeof(float), vel->size(), f) == vel->size();
+    *p = hd.params;
+    *step = hd.step;
+  }
+  std::fclose(f);
+  return ok;
+}
+
+// side^3 jittered lattice at rest spacing in the tank corner; tank = twice the block (dam break).
+void dam_break_block(int side, uint64_t seed, sph_params* p, std::vector<float>* pos, std::vector<float>* vel) {
+  const double d = std::cbrt((double)p->mass / (double)p->rho0);
+  p->tank_size = (float)(2.0 * side * d);
+  const size_t n = (size_t)side * side * side;
+  pos->resize(n * 3);
+  vel->assign(n * 3, 0.0f);
+  uint64_t s = seed * 2862933555777941757ull + 3037000493ull;
+  for (size_t i = 0; i < n; i++) {
+    const size_t ijk[3] = {i / ((size_t)side * side), (i / side) % side, i % side};
+    for (int a = 0; a < 3; a++) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      const double u = (double)(s >> 11) / 9007199254740992.0;  // [0,1)
+      (*pos)[3 * i + a] = (float)((ijk[a] + 0.5) * d + (2.0 * u - 1.0) * 0.1 * d);
+    }
+  }
+}
+
+void usage() {
+  std::puts(
+      "sph_headless [--n N] [--scene random|dam] [--side S] [--steps K] [--seed X] [--mode shim|resident]\n"
+      "             [--dump-every D] [--out PREFIX] [--resume FILE] [--exact]");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  int n = 3000, steps = 100, side = 30, dump_every = 0;  // numParticles = 3000: main.cpp:8
+  uint64_t seed = 12345;
+  bool exact = false;
+  std::string scene = "random", mode = "resident", out = "sph_dump", resume;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto val = [&](const char* name) -> const char* {
+      if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(2); }
+      return argv[++i];
+    };
+    if (a == "--n") n = std::atoi(val("--n"));
+    else if (a == "--steps") steps = std::atoi(val("--steps"));
+    else if (a == "--side") side = std::atoi(val("--side"));
+    else if (a == "--seed") seed = std::strtoull(val("--seed"), nullptr, 10);
+    else if (a == "--scene") scene = val("--scene");
+    else if (a == "--mode") mode = val("--mode");
+    else if (a == "--dump-every") dump_every = std::atoi(val("--dump-every"));
+    else if (a == "--out") out = val("--out");
+    else if (a == "--resume") resume = val("--resume");
+    else if (a == "--exact") exact = true;
+    else { usage(); return a == "--help" ? 0 : 2; }
+  }
+
+  sph_params p;
+  sph_params_default(&p);
+  std::vector<float> pos, vel;
+  uint32_t step0 = 0;
+  if (!resume.empty()) {
+    if (!read_dump(resume, &p, &step0, &pos, &vel)) { std::fprintf(stderr, "cannot read %s\n", resume.c_str()); return 1; }
+  } else if (scene == "dam") {
+    dam_break_block(side, seed, &p, &pos, &vel);
+  } else {
+    // the reference's own scene, through the drop-in initParticles (main.cpp:27)
+    std::string env = "SPH_AMD_SEED=" + std::to_string(seed);
+    putenv(const_cast<char*>(env.c_str()));
+    float *pp = nullptr, *vv = nullptr;
+    initParticles(&pp, &vv, n);
+    pos.assign(pp, pp + (size_t)n * 3);
+    vel.assign(vv, vv + (size_t)n * 3);
+    std::free(pp);  // main.cpp:37-39 releases with free(): the shim allocates with malloc
+    std::free(vv);
+  }
+  if (exact) p.flags |= SPH_FLAG_EXACT_ORDER;
+  n = (int)(pos.size() / 3);
+  tankSize = p.tank_size;  // the shim path reads the reference's globals (main.cpp:12)
+  a_gravity[0] = p.gravity[0]; a_gravity[1] = p.gravity[1]; a_gravity[2] = p.gravity[2];
+  if (exact) setenv("SPH_AMD_EXACT", "1", 1);
+
+  sph_context* ctx = nullptr;
+  if (mode == "resident") {
+    if (sph_create(&p, n, 0, &ctx) != SPH_OK || sph_upload(ctx, pos.data(), vel.data(), n) != SPH_OK) {
+      std::fprintf(stderr, "sph_amd: %s\n", sph_last_error());
+      return 1;
+    }
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  for (int s = 1; s <= steps; s++) {
+    if (ctx) {
+      if (sph_step(ctx, 1) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
+    } else {
+      updateParticles(pos.data(), vel.data(), n);  // main.cpp:33
+    }
+    if (dump_every > 0 && s % dump_every == 0) {  // main.cpp:34, display() -> dump
+      if (ctx && sph_download(ctx, pos.data(), vel.data()) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
+      char name[512];
+      std::snprintf(name, sizeof name, "%s_%06u.sphd", out.c_str(), step0 + s);
+      if (!write_dump(name, p, step0 + s, pos, vel)) { std::fprintf(stderr, "cannot write %s\n", name); return 1; }
+    }
+  }
+  if (ctx && sph_download(ctx, pos.data(), vel.data()) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  double cx = 0, cy = 0, cz = 0;
+  for (int i = 0; i < n; i++) { cx += pos[3 * i]; cy += pos[3 * i + 1]; cz += pos[3 * i + 2]; }
+  std::printf("{\"n\": %d, \"steps\": %d, \"mode\": \"%s\", \"seconds\": %.6f, \"particle_updates_per_s\": %.4e, "
+              "\"centre_of_mass\": [%.6f, %.6f, %.6f]}\n",
+              n, steps, mode.c_str(), sec, (double)n * steps / sec, cx / n, cy / n, cz / n);
+  char name[512];
+  std::snprintf(name, sizeof name, "%s_final.sphd", out.c_str());
+  if (!write_dump(name, p, step0 + steps, pos, vel)) { std::fprintf(stderr, "cannot write %s\n", name); return 1; }
+  if (ctx) sph_destroy(ctx);
+  return 0;
+}

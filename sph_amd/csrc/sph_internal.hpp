@@ -32,6 +32,23 @@ struct State {
   int32_t* id;
 };
 
+// Grid-sorted working copy of the state, packed for neighbour gathers (one 16-byte load per array).
+struct Sorted {
+  float4* pos;  // x, y, z, unused
+  float4* vel;  // vx, vy, vz, density (w is written by the density pass)
+  int32_t* id;
+};
+
+// Which candidates of a particle's flattened 27-cell stencil are neighbours (distance test passed), one
+// bit per candidate, written by the density pass and walked by the force pass.  Word w of particle slot s
+// lives at words[w * stride + s]; ncand[s] is the number of candidates (bits) of slot s.
+constexpr int kMaskWords = 16;
+struct NeighbourMask {
+  uint32_t* words;
+  int32_t* ncand;
+  size_t stride;
+};
+
 struct GridBuffers {
   // ncells counts the real cells PLUS one trailing trash cell for particles outside the local grid.
   int32_t* count;      // [ncells]   histogram, left zeroed by the scan
@@ -53,14 +70,18 @@ struct DebugBuffers {
 
 constexpr int kScanItems = 4096;  // cells per scan block
 
+// Flavour of the density/force sweeps: queued is the default; the others exist for verification and ablation.
+enum SweepMode { SWEEP_QUEUED = 0, SWEEP_PLAIN = 1, SWEEP_EXACT = 2 };
+
 void launch_split_aos(hipStream_t s, const float* pos_aos, const float* vel_aos, int n, State st);
 void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, GridBuffers g);
 void launch_scan(hipStream_t s, GridBuffers g);
-void launch_reorder(hipStream_t s, const State& in, const State& out, int n, GridBuffers g);
-void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, const GridBuffers& g,
-                    float* rho, int32_t* ncount, bool exact);
-void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
-                  const GridBuffers& g, const float* rho, float* force_dbg, int32_t* n_own_out, bool exact);
+void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g);
+void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
+                    int32_t* ncount, const NeighbourMask& nm, SweepMode mode);
+void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,
+                  const GridBuffers& g, float* force_dbg, int32_t* n_own_out, const NeighbourMask& nm,
+                  SweepMode mode);
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
                       bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters);
 void launch_slab_append(hipStream_t s, const float* rec, int n_rec, const State& st, int at);
@@ -68,10 +89,10 @@ void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, con
 void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
-                       const float* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       const float4* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
                        float* rho, float* force, int32_t* ncount, int32_t* cell);
 void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos);
-void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float* rho_s,
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float4* rho_s,
                          const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
                          float* rho, float* force, int32_t* ncount, int32_t* cell);
 

@@ -6,10 +6,8 @@
 //   k_scan_*    exclusive prefix sum over the histogram -> cell start table
 //   k_scatter / k_reorder   counting sort; inside a cell particles end up in ascending id order,
 //               so the summation order of every later pass is a pure function of (positions, ids)
-//   k_density   rho_i = sum_j m*Wpoly6(r_ij)                                   (:131-150)
-//   k_force     pressure + viscosity + gravity + surface tension, symplectic Euler, tank walls
-//                                                                              (:153-319)
-#include "sph_internal.hpp"
+//   density and force sweeps: sph_sweeps.hip
+#include "sph_device.hpp"
 
 namespace sph {
 
@@ -18,44 +16,6 @@ namespace {
 constexpr int kBlock = 256;
 
 __host__ __device__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
-
-// ---- cell index ---------------------------------------------------------------------------------
-// c = clamp(floorf(x / cell), 0, gn-1) - offset, clamped to the local grid.  True fp32 division:
-// x * (1/cell) rounds differently.  fmaxf(NaN, 0) = 0 keeps NaN positions inside the table.
-__device__ inline int cell_coord(float x, float cell, int gn) {
-  float q = floorf(x / cell);
-  q = fminf(fmaxf(q, 0.0f), (float)(gn - 1));
-  return (int)q;
-}
-
-// ---- smoothing kernels, reference compute.cpp:41-95 (callers guarantee r <= h) ---------------------
-__device__ inline float w_poly6(const DevParams& P, float r) {  // :61-71
-  float rr = r * r;
-  float d = P.h2 - rr;
-  float d3 = d * d * d;
-  return (float)(P.c_poly6 * (double)d3);
-}
-__device__ inline float grad_spiky(const DevParams& P, float r) {  // :50-59
-  float d = P.h - r;
-  float d2 = d * d;
-  return (float)(P.c_spiky_grad * (double)d2);
-}
-__device__ inline float lapl_visc(const DevParams& P, float r) {  // :41-48
-  return (float)(P.c_visc_lapl * (double)(P.h - r));
-}
-__device__ inline float grad_poly6(const DevParams& P, float r) {  // :73-83
-  float rr = r * r;
-  float d = P.h2 - rr;
-  float d2 = d * d;
-  return (float)(P.c_poly6_grad * (double)r * (double)d2);
-}
-__device__ inline float lapl_poly6(const DevParams& P, float r) {  // :85-95
-  float rr = r * r;
-  float d = P.h2 - rr;
-  float d2 = d * d;
-  float poly = 4.0f * rr * d - d2;
-  return (float)(P.c_poly6_lapl * (double)poly);
-}
 
 // ---- AoS <-> SoA ------------------------------------------------------------------------------------
 __global__ void k_split_aos(const float* __restrict__ pos, const float* __restrict__ vel, int n, State st) {
@@ -86,13 +46,13 @@ __global__ void k_gather_aos(State st, int n, float* __restrict__ pos, float* __
   }
 }
 
-__global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const float* rho_s,
+__global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const float4* velrho_s,
                                const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
                                float* rho, float* force, int32_t* ncount, int32_t* cell) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   int i = id[s];
-  if (rho) rho[i] = rho_s[s];
+  if (rho) rho[i] = velrho_s[s].w;
   if (force) {
     force[3 * i + 0] = force_s[s];
     force[3 * i + 1] = force_s[(size_t)n + s];
@@ -243,7 +203,7 @@ __global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int3
 
 // Final slot = cell start + number of cell-mates with a smaller id: the in-cell order no longer depends
 // on the order in which the histogram atomics happened to be served.
-__global__ void k_reorder(int n, State in, State out, const int32_t* __restrict__ cell_of,
+__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ cell_of,
                           const int32_t* __restrict__ start, const int32_t* __restrict__ src_of,
                           const int32_t* __restrict__ id_prov, int32_t* __restrict__ cell_s) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,239 +215,10 @@ __global__ void k_reorder(int n, State in, State out, const int32_t* __restrict_
   int r = 0;
   for (int t = b; t < e; t++) r += id_prov[t] < my;
   int d = b + r;
-  out.x[d] = in.x[i];
-  out.y[d] = in.y[i];
-  out.z[d] = in.z[i];
-  out.vx[d] = in.vx[i];
-  out.vy[d] = in.vy[i];
-  out.vz[d] = in.vz[i];
+  out.pos[d] = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
+  out.vel[d] = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
   out.id[d] = my;
   cell_s[d] = c;
-}
-
-// ---- neighbour sweeps --------------------------------------------------------------------------------------
-// Cells are linearised as c = (cx*ny + cy)*nz + cz: z varies fastest and x, the slab-decomposition axis,
-// slowest, so every x-column of cells is one contiguous slot range.  The 27-cell stencil of a particle is
-// 9 rows of (up to) 3 z-adjacent cells, and each row is ONE contiguous slot range.  Rows are visited
-// dx-major, dy-minor.
-struct Stencil {
-  int b[9], e[9];
-};
-
-__device__ inline void stencil_ranges(const DevParams& P, const int32_t* __restrict__ start, int c, Stencil& st) {
-  int cz = c % P.nz;
-  int t = c / P.nz;
-  int cy = t % P.ny;
-  int cx = t / P.ny;
-  int z0 = cz > 0 ? cz - 1 : 0;
-  int z1 = cz < P.nz - 1 ? cz + 1 : P.nz - 1;
-  int k = 0;
-#pragma unroll
-  for (int dx = -1; dx <= 1; dx++) {
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++, k++) {
-      int x = cx + dx, y = cy + dy;
-      bool ok = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
-      int row = ok ? (x * P.ny + y) * P.nz : 0;
-      st.b[k] = ok ? start[row + z0] : 0;
-      st.e[k] = ok ? start[row + z1 + 1] : 0;
-    }
-  }
-}
-
-__device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
-
-// Density: rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (reference compute.cpp:131-150).
-template <bool EXACT>
-__global__ void __launch_bounds__(kBlock) k_density(DevParams P, State st, int n, const int32_t* __restrict__ start,
-                                                    const int32_t* __restrict__ cell_s, float* __restrict__ rho,
-                                                    int32_t* __restrict__ ncount) {
-  // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
-  const int cpc = P.ny * P.nz;
-  int s = start[P.dens_lo * cpc] + blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= start[P.dens_hi * cpc]) return;
-  float xi = st.x[s], yi = st.y[s], zi = st.z[s];
-  Stencil sc;
-  stencil_ranges(P, start, cell_s[s], sc);
-  float acc = 0.0f;
-  int cnt = 0;
-  if (!EXACT) {
-#pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-      for (int j = sc.b[k]; j < sc.e[k]; j++) {
-        float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
-        if (r2 <= P.r2_max) {
-          acc += P.m * w_poly6(P, sqrtf(r2));
-          cnt++;
-        }
-      }
-    }
-  } else {
-    // ascending particle id: the order in which the reference's j loop meets the non-zero terms
-    int last = -1;
-    for (;;) {
-      int best = 0x7fffffff;
-      float best_r2 = 0.0f;
-#pragma unroll 1
-      for (int k = 0; k < 9; k++) {
-        for (int j = sc.b[k]; j < sc.e[k]; j++) {
-          float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
-          int idj = st.id[j];
-          if (r2 <= P.r2_max && idj > last && idj < best) {
-            best = idj;
-            best_r2 = r2;
-          }
-        }
-      }
-      if (best == 0x7fffffff) break;
-      acc += P.m * w_poly6(P, sqrtf(best_r2));
-      cnt++;
-      last = best;
-    }
-  }
-  rho[s] = acc;
-  if (ncount) ncount[s] = cnt;
-}
-
-struct ForceAcc {
-  float px, py, pz;  // pressure          :159
-  float vx, vy, vz;  // viscosity         :192
-  float gx, gy, gz;  // colour gradient   :229
-  float lapl;        // colour laplacian  :230
-};
-
-// One neighbour's contribution to the three pair sums of the reference (:161-179, :194-209, :233-253).
-__device__ inline void pair_terms(const DevParams& P, float dx, float dy, float dz, float r2, float pi,
-                                  float rho_j, float dvx, float dvy, float dvz, ForceAcc& a) {
-  float r = sqrtf(r2);
-  float ux = 0.0f, uy = 0.0f, uz = 0.0f;  // vecNormalize(r, r)  :28-39
-  if (r > 0.0f) {
-    ux = dx / r;
-    uy = dy / r;
-    uz = dz / r;
-  }
-  float pj = P.c2 * (rho_j - P.rho0);                                    // :164
-  float mfp = P.neg_m * (pi + pj) / (2.0f * rho_j) * grad_spiky(P, r);  // :170
-  a.px += mfp * ux;
-  a.py += mfp * uy;
-  a.pz += mfp * uz;
-  float t = P.visc_m * lapl_visc(P, r) / rho_j;  // :204
-  a.vx += dvx * t;
-  a.vy += dvy * t;
-  a.vz += dvz * t;
-  if (P.tension) {
-    float mg = P.m * grad_poly6(P, r) / rho_j;  // :242
-    a.gx += ux * mg;
-    a.gy += uy * mg;
-    a.gz += uz * mg;
-    a.lapl += P.m * lapl_poly6(P, r) / rho_j;  // :252
-  }
-}
-
-template <bool EXACT>
-__global__ void __launch_bounds__(kBlock) k_force(DevParams P, State st, State out, int n,
-                                                  const int32_t* __restrict__ start,
-                                                  const int32_t* __restrict__ cell_s,
-                                                  const float* __restrict__ rho, float* __restrict__ force_dbg,
-                                                  int32_t* __restrict__ n_own_out) {
-  // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
-  const int cpc = P.ny * P.nz;
-  const int base = start[P.own_lo * cpc], bound = start[P.own_hi * cpc];
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o == 0 && n_own_out) {
-    const int real = P.nx * cpc;
-    n_own_out[0] = bound - base;                    // particles this context keeps
-    n_own_out[1] = start[real + 1] - start[real];   // trash cell: particles outside the local grid
-  }
-  const int s = base + o;
-  if (s >= bound) return;
-  float xi = st.x[s], yi = st.y[s], zi = st.z[s];
-  float vxi = st.vx[s], vyi = st.vy[s], vzi = st.vz[s];
-  float rho_i = rho[s];
-  float pi = P.c2 * (rho_i - P.rho0);  // :158
-  Stencil sc;
-  stencil_ranges(P, start, cell_s[s], sc);
-  ForceAcc a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (!EXACT) {
-#pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-      for (int j = sc.b[k]; j < sc.e[k]; j++) {
-        float dx = xi - st.x[j], dy = yi - st.y[j], dz = zi - st.z[j];
-        float r2 = dist2(dx, dy, dz);
-        if (r2 <= P.r2_max)
-          pair_terms(P, dx, dy, dz, r2, pi, rho[j], st.vx[j] - vxi, st.vy[j] - vyi, st.vz[j] - vzi, a);
-      }
-    }
-  } else {
-    int last = -1;
-    for (;;) {
-      int best = 0x7fffffff, bj = -1;
-#pragma unroll 1
-      for (int k = 0; k < 9; k++) {
-        for (int j = sc.b[k]; j < sc.e[k]; j++) {
-          float r2 = dist2(xi - st.x[j], yi - st.y[j], zi - st.z[j]);
-          int idj = st.id[j];
-          if (r2 <= P.r2_max && idj > last && idj < best) {
-            best = idj;
-            bj = j;
-          }
-        }
-      }
-      if (bj < 0) break;
-      float dx = xi - st.x[bj], dy = yi - st.y[bj], dz = zi - st.z[bj];
-      pair_terms(P, dx, dy, dz, dist2(dx, dy, dz), pi, rho[bj], st.vx[bj] - vxi, st.vy[bj] - vyi,
-                 st.vz[bj] - vzi, a);
-      last = best;
-    }
-  }
-  // f_total = (((0 + pressure) + viscosity) + gravity*rho) + tension   (:181-183,:211-213,:220-222,:259-261)
-  float fx = 0.0f + a.px, fy = 0.0f + a.py, fz = 0.0f + a.pz;
-  fx += a.vx;
-  fy += a.vy;
-  fz += a.vz;
-  fx += P.gx * rho_i;
-  fy += P.gy * rho_i;
-  fz += P.gz * rho_i;
-  if (P.tension) {
-    float len = sqrtf(a.gx * a.gx + a.gy * a.gy + a.gz * a.gz);  // vecNormalize(gradcolor)  :255
-    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-    if (len > 0.0f) {
-      nx = a.gx / len;
-      ny = a.gy / len;
-      nz = a.gz / len;
-    }
-    float t = P.neg_sigma * a.lapl;  // :257
-    fx += t * nx;
-    fy += t * ny;
-    fz += t * nz;
-  }
-  if (force_dbg) {
-    force_dbg[o] = fx;
-    force_dbg[(size_t)n + o] = fy;
-    force_dbg[2 * (size_t)n + o] = fz;
-  }
-  // symplectic Euler (:265-280)
-  float scl = P.dt / rho_i;
-  vxi += fx * scl;
-  vyi += fy * scl;
-  vzi += fz * scl;
-  xi = xi + vxi * P.dt;
-  yi = yi + vyi * P.dt;
-  zi = zi + vzi * P.dt;
-  // tank walls, damping 1 (:286-319)
-  if (xi < 0.0f) { xi = 0.0f; vxi = -1.0f * vxi; }
-  if (xi > P.tank) { xi = P.tank; vxi = -1.0f * vxi; }
-  if (yi < 0.0f) { yi = 0.0f; vyi = -1.0f * vyi; }
-  if (yi > P.tank) { yi = P.tank; vyi = -1.0f * vyi; }
-  if (zi < 0.0f) { zi = 0.0f; vzi = -1.0f * vzi; }
-  if (zi > P.tank) { zi = P.tank; vzi = -1.0f * vzi; }
-  out.x[o] = xi;
-  out.y[o] = yi;
-  out.z[o] = zi;
-  out.vx[o] = vxi;
-  out.vy[o] = vyi;
-  out.vz[o] = vzi;
-  if (out.id) out.id[o] = st.id[s];
 }
 
 // ---- slab decomposition: halo/migration records ---------------------------------------------------------------
@@ -566,13 +297,13 @@ __global__ void k_join_aos(State st, int n, float* __restrict__ pos, float* __re
 // Intermediates of the last step for the own particles, in the order the new state was written
 // (index o <-> sorted slot base + o).
 __global__ void k_join_debug(DevParams P, const int32_t* __restrict__ start, int n_own, int n_stride,
-                             const float* __restrict__ rho_s, const float* __restrict__ force_o,
+                             const float4* __restrict__ velrho_s, const float* __restrict__ force_o,
                              const int32_t* __restrict__ ncount_s, const int32_t* __restrict__ cell_s,
                              float* rho, float* force, int32_t* ncount, int32_t* cell) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n_own) return;
   int s = start[P.own_lo * P.ny * P.nz] + o;
-  if (rho) rho[o] = rho_s[s];
+  if (rho) rho[o] = velrho_s[s].w;
   if (force) {
     force[3 * o + 0] = force_o[o];
     force[3 * o + 1] = force_o[(size_t)n_stride + o];
@@ -609,32 +340,12 @@ void launch_scan(hipStream_t s, GridBuffers g) {
   hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start);
 }
 
-void launch_reorder(hipStream_t s, const State& in, const State& out, int n, GridBuffers g) {
+void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, g.cell_of, g.rank_of, g.start,
                      in.id, g.src_of, g.id_prov);
   hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.cell_of, g.start,
                      g.src_of, g.id_prov, g.cell_s);
-}
-
-void launch_density(hipStream_t s, const DevParams& P, const State& st, int n, const GridBuffers& g, float* rho,
-                    int32_t* ncount, bool exact) {
-  if (n <= 0) return;
-  dim3 grid(div_up(n, kBlock)), block(kBlock);
-  if (exact)
-    hipLaunchKernelGGL(k_density<true>, grid, block, 0, s, P, st, n, g.start, g.cell_s, rho, ncount);
-  else
-    hipLaunchKernelGGL(k_density<false>, grid, block, 0, s, P, st, n, g.start, g.cell_s, rho, ncount);
-}
-
-void launch_force(hipStream_t s, const DevParams& P, const State& st, const State& out, int n,
-                  const GridBuffers& g, const float* rho, float* force_dbg, int32_t* n_own_out, bool exact) {
-  if (n <= 0) return;
-  dim3 grid(div_up(n, kBlock)), block(kBlock);
-  if (exact)
-    hipLaunchKernelGGL(k_force<true>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg, n_own_out);
-  else
-    hipLaunchKernelGGL(k_force<false>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, rho, force_dbg, n_own_out);
 }
 
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
@@ -660,7 +371,7 @@ void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* v
 }
 
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
-                       const float* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       const float4* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
                        float* rho, float* force, int32_t* ncount, int32_t* cell) {
   if (n_own <= 0) return;
   hipLaunchKernelGGL(k_join_debug, dim3(div_up(n_own, kBlock)), dim3(kBlock), 0, s, P, start, n_own, n_stride,
@@ -676,7 +387,7 @@ void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, fl
   hipLaunchKernelGGL(k_gather_aos, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, st, n, pos_aos, vel_aos);
 }
 
-void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float* rho_s, const float* force_s,
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float4* rho_s, const float* force_s,
                          const int32_t* ncount_s, const int32_t* cell_s, float* rho, float* force,
                          int32_t* ncount, int32_t* cell) {
   if (n <= 0) return;

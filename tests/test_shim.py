@@ -1,0 +1,139 @@
+"""The drop-in boundary: libsph_compute.so must look like the reference's compute.o to its callers
+(reference compute/compute.h:4-8, main.cpp:12,27,33, render.cpp:133)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT, bits_equal, max_rel
+
+from sph_amd import dumpio, scenes
+from sph_amd.params import default_params
+
+SHIM = os.path.join(ROOT, "sph_amd", "libsph_compute.so")
+HEADLESS = os.path.join(ROOT, "sph_amd", "sph_headless")
+REF_HEADER_DIR = "/root/reference/compute"
+
+MANGLED = {  # Itanium names of the reference's three C++-linkage entry points
+    "initParticles": "_Z13initParticlesPPfS0_i",
+    "updateParticles": "_Z15updateParticlesPfS_i",
+    "vecNormalize": "_Z12vecNormalizePKfPf",
+}
+GLOBALS = {"soundSpeed": 1.0, "m": 0.00020543, "rho0": 600.0, "dynVisc": 0.2, "timestep": 0.005,
+           "tankSize": 0.2154, "surfTension": 0.0728, "h": 0.01}
+
+
+@pytest.fixture(scope="module")
+def shim():
+    import sph_amd.capi as capi
+    capi.load()  # one HIP runtime per process (see capi.load)
+    return C.CDLL(SHIM)
+
+
+def test_exports_reference_symbols(shim):
+    for name in MANGLED.values():
+        assert hasattr(shim, name), name
+    for name, value in GLOBALS.items():
+        assert C.c_float.in_dll(shim, name).value == np.float32(value), name
+    g = (C.c_float * 3).in_dll(shim, "a_gravity")
+    assert tuple(g) == (0.0, -10.0, 0.0)
+    for name in ("h2", "h6", "h9"):  # zero until initParticles runs, like the reference (compute.cpp:18-20)
+        C.c_float.in_dll(shim, name)
+
+
+def test_vec_normalize_matches_reference(shim):
+    fn = getattr(shim, MANGLED["vecNormalize"])
+    with np.load(os.path.join(GOLDEN_DIR, "kernels.npz")) as z:
+        for a, want in zip(z["vecnorm_in"], z["vecnorm_out"]):
+            a = np.ascontiguousarray(a, np.float32)
+            b = np.empty(3, np.float32)
+            fn(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+            assert bits_equal(b, want)
+            fn(a.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))  # in place, as compute.cpp:174 does
+            assert bits_equal(a, want)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_HEADER_DIR) or shutil.which("g++") is None,
+                    reason="needs the reference checkout (build container only)")
+def test_links_against_the_reference_header(tmp_path):
+    """A translation unit that includes the REFERENCE's own compute.h links against the shim."""
+    src = tmp_path / "caller.cpp"
+    src.write_text(
+        '#include <cstdio>\n#include "compute.h"\nextern float tankSize;\n'
+        "int main() { float a[3] = {3, 4, 0}, b[3]; vecNormalize(a, b);\n"
+        "  void (*u)(float*, float*, int) = updateParticles; void (*i)(float**, float**, int) = initParticles;\n"
+        '  std::printf("%g %g %g %g %d\\n", b[0], b[1], b[2], tankSize, u != nullptr && i != nullptr); return 0; }\n')
+    exe = tmp_path / "caller"
+    libdir = os.path.join(ROOT, "sph_amd")
+    subprocess.run(["g++", "-std=c++11", f"-I{REF_HEADER_DIR}", str(src), "-o", str(exe), f"-L{libdir}",
+                    "-lsph_compute", "-lsph_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["0.6", "0.8", "0", "0.2154", "1"]
+
+
+@pytest.mark.gpu
+def test_update_particles_through_the_shim(shim, oracle):
+    init = getattr(shim, MANGLED["initParticles"])
+    upd = getattr(shim, MANGLED["updateParticles"])
+    os.environ["SPH_AMD_SEED"] = "42"
+    pp, vv = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    n = 3000  # main.cpp:8
+    init(C.byref(pp), C.byref(vv), n)
+    pos = np.ctypeslib.as_array(pp, shape=(n, 3))
+    vel = np.ctypeslib.as_array(vv, shape=(n, 3))
+    assert pos.min() >= 0 and pos.max() <= np.float32(0.2154) / 2 and np.all(vel == 0)
+    assert C.c_float.in_dll(shim, "h2").value == np.float32(0.01) * np.float32(0.01)
+    p = default_params()
+    po, vo = pos.copy(), vel.copy()
+    for _ in range(3):
+        upd(pp, vv, n)
+        oracle.step_allpairs(p, po, vo)
+    assert max_rel(pos, po) <= 3e-5 and max_rel(vel, vo) <= 1e-4
+    # the reference's globals are the configuration API: tilt gravity and step again
+    g = (C.c_float * 3).in_dll(shim, "a_gravity")
+    g[0], g[1] = 5.0, -8.0
+    q = default_params()
+    q.gravity[0], q.gravity[1] = 5.0, -8.0
+    upd(pp, vv, n)
+    oracle.step_allpairs(q, po, vo)
+    assert max_rel(pos, po) <= 5e-5
+    g[0], g[1] = 0.0, -10.0
+    libc = C.CDLL(None)
+    libc.free(pp)  # main.cpp:37-39 frees with free()
+    libc.free(vv)
+
+
+@pytest.mark.gpu
+def test_headless_driver_modes_and_resume(tmp_path, oracle):
+    """Fixed-step loop, dumps and resume; `--exact` makes the drop-in path bit-identical to the
+    reference algorithm, so shim mode, resident mode and the oracle agree to the last bit."""
+    def run(*args):
+        r = subprocess.run([HEADLESS, *args], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        return r.stdout
+
+    run("--n", "1500", "--seed", "9", "--steps", "6", "--mode", "resident", "--exact", "--dump-every", "3", "--out", "res")
+    run("--n", "1500", "--seed", "9", "--steps", "6", "--mode", "shim", "--exact", "--out", "shim")
+    pr, s3, pos3, vel3 = dumpio.read_dump(tmp_path / "res_000003.sphd")
+    _, s6, pos6, vel6 = dumpio.read_dump(tmp_path / "res_final.sphd")
+    _, _, spos6, svel6 = dumpio.read_dump(tmp_path / "shim_final.sphd")
+    assert (s3, s6) == (3, 6) and pos6.shape == (1500, 3)
+    assert bits_equal(pos6, spos6) and bits_equal(vel6, svel6)
+    # resume from the step-3 dump and land on the same state
+    run("--resume", "res_000003.sphd", "--steps", "3", "--mode", "resident", "--exact", "--out", "cont")
+    _, s, cpos, cvel = dumpio.read_dump(tmp_path / "cont_final.sphd")
+    assert s == 6 and bits_equal(cpos, pos6) and bits_equal(cvel, vel6)
+    # and the oracle, started from the step-3 dump, agrees bit for bit
+    p = default_params()
+    po, vo = pos3.copy(), vel3.copy()
+    for _ in range(3):
+        oracle.step_allpairs(p, po, vo)
+    assert bits_equal(po, pos6) and bits_equal(vo, vel6)
+    # python writer round-trips through the C++ reader
+    dumpio.write_dump(tmp_path / "py.sphd", p, 0, pos3, vel3)
+    run("--resume", "py.sphd", "--steps", "3", "--mode", "resident", "--exact", "--out", "py")
+    _, _, ppos, _ = dumpio.read_dump(tmp_path / "py_final.sphd")
+    assert bits_equal(ppos, pos6)
