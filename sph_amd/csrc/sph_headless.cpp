@@ -11,7 +11,7 @@
 //                    (host arrays valid after every call, as display() expects, render.cpp:240-253)
 //   --mode resident  state stays in HBM between steps (sph_upload once, sph_step, sph_download at dumps)
 //
-// Dump file: 64-byte header {magic "SPHD", u32 version=1, u32 n, u32 step, sph_params (52 bytes)}, then
+// Dump file: header {magic "SPHD", u32 version=1, u32 n, u32 step, sph_params (56 bytes)} = 72 bytes, then
 // float32 pos[3n], float32 vel[3n].  A dump is also a checkpoint: --resume FILE continues from it.
 #include <chrono>
 #include <cmath>
