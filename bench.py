@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
 BYTES_PER_PARTICLE = {
     "hash": 16,      # R pos 12, W cell 4
     "reorder": 56,   # R key 4 (histogram) ; R key 4 + R pos,vel 24 + W pos,vel 24 (scatter)
+    "search": 12,    # R pos 12 (+ neighbour bitmask W, 4 B per 32 candidates)
     "density": 16,   # R pos 12, W rho 4
     "force": 52,     # R pos 12, vel 12, rho 4 ; W pos 12, vel 12
 }
@@ -169,7 +170,7 @@ def main():
     }
     if not args.no_events and tm["steps"] > 0:
         k = tm["steps"]
-        per = {name: tm[name + "_ms"] / k for name in ("hash", "scan", "reorder", "density", "force")}
+        per = {name: tm[name + "_ms"] / k for name in ("hash", "scan", "reorder", "search", "density", "force")}
         force_s = per["force"] * 1e-3
         achieved = BYTES_PER_PARTICLE["force"] * n / force_s / 1e9
         out["roofline"] = {
@@ -177,7 +178,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(r["workload"]),
             "bytes_per_particle": BYTES_PER_PARTICLE["force"], "avg_launch_ms": per["force"],
         }
-        df = (BYTES_PER_PARTICLE["density"] + BYTES_PER_PARTICLE["force"]) * n / ((per["density"] + per["force"]) * 1e-3) / 1e9
+        df = (BYTES_PER_PARTICLE["density"] + BYTES_PER_PARTICLE["force"]) * n / (
+            (per["search"] + per["density"] + per["force"]) * 1e-3) / 1e9
         out["roofline_density_force"] = {"bound": "hbm", "achieved": df, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": df / HBM_PEAK_GBS, "bytes_per_particle": 68}
         out["kernel_ms_per_step"] = per

@@ -85,6 +85,7 @@ typedef struct sph_timings {
   double hash_ms;       /* cell hash + histogram                        */
   double scan_ms;       /* prefix sum over cell counts                  */
   double reorder_ms;    /* scatter + in-cell id ordering + state gather */
+  double search_ms;     /* neighbour search: distance tests -> per-particle neighbour bitmask */
   double density_ms;    /* density pass  (reference compute.cpp:131-150) */
   double force_ms;      /* pressure+viscosity+gravity+tension+integrate+walls (:153-319) */
   double other_ms;      /* pack/unpack, memsets                          */
@@ -124,7 +125,7 @@ int sph_upload_device(sph_context* ctx, const float* d_pos_aos, const float* d_v
 
 /*
  * Advance nsteps time steps; each step is one updateParticles (compute.cpp:120-320):
- * cell hash -> counting sort -> density -> forces -> integrate -> tank walls.
+ * cell hash -> counting sort -> neighbour search -> density -> forces -> integrate -> tank walls.
  * Asynchronous on the context's stream; sph_download / sph_sync wait for it.
  */
 int sph_step(sph_context* ctx, int nsteps);

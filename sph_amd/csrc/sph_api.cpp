@@ -31,7 +31,7 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SPH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-enum Cat { CAT_HASH, CAT_SCAN, CAT_REORDER, CAT_DENSITY, CAT_FORCE, CAT_OTHER, CAT_N };
+enum Cat { CAT_HASH, CAT_SCAN, CAT_REORDER, CAT_SEARCH, CAT_DENSITY, CAT_FORCE, CAT_OTHER, CAT_N };
 
 struct EventPair {
   int cat;
@@ -69,7 +69,7 @@ struct sph_context {
   bool timing = false;
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
-  double acc_ms[CAT_N] = {0, 0, 0, 0, 0, 0};
+  double acc_ms[CAT_N] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t acc_steps = 0, acc_particles = 0;
 };
 
@@ -261,9 +261,10 @@ int one_step(sph_context* c) {
   { Timed t(c, CAT_HASH); launch_hash(c->stream, c->dev, c->cur, n, c->grid); }
   { Timed t(c, CAT_SCAN); launch_scan(c->stream, c->grid); }
   { Timed t(c, CAT_REORDER); launch_reorder(c->stream, c->cur, c->sorted, n, c->grid); }
-  SweepMode mode = SWEEP_QUEUED;
+  SweepMode mode = SWEEP_MASKED;
   if (exact) mode = SWEEP_EXACT;
   else if (c->params.flags & SPH_FLAG_LANE_SWEEP) mode = SWEEP_PLAIN;
+  if (mode == SWEEP_MASKED) { Timed t(c, CAT_SEARCH); launch_neighbours(c->stream, c->dev, c->sorted, n, c->grid, c->nmask); }
   { Timed t(c, CAT_DENSITY);
     launch_density(c->stream, c->dev, c->sorted, n, c->grid, keep ? c->dbg.ncount : nullptr, c->nmask, mode); }
   State out = c->cur;
@@ -334,7 +335,7 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
   const size_t n = (size_t)n_max;
   if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n)) || (rc = dev_alloc(&c->sorted.vel, n)) ||
       (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)kMaskWords * n)) ||
-      (rc = dev_alloc(&c->nmask.ncand, n)))
+      (rc = dev_alloc(&c->nmask.ncand, n)) || (rc = dev_alloc(&c->nmask.nnb, n)))
     return bail(rc);
   c->nmask.stride = n;
   // scan kernels read/write whole 4096-cell tiles through int4: round the tables up to a tile
@@ -403,7 +404,7 @@ int sph_destroy(sph_context* c) {
   for (auto e : c->pool) (void)hipEventDestroy(e);
   free_state(&c->cur);
   (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.vel); (void)hipFree(c->sorted.id);
-  (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand);
+  (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand); (void)hipFree(c->nmask.nnb);
   (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.block_sums);
   (void)hipFree(c->grid.cell_of); (void)hipFree(c->grid.rank_of); (void)hipFree(c->grid.src_of);
   (void)hipFree(c->grid.id_prov); (void)hipFree(c->grid.cell_s);
@@ -552,6 +553,7 @@ int sph_get_timings(sph_context* c, sph_timings* out) {
   out->hash_ms = c->acc_ms[CAT_HASH];
   out->scan_ms = c->acc_ms[CAT_SCAN];
   out->reorder_ms = c->acc_ms[CAT_REORDER];
+  out->search_ms = c->acc_ms[CAT_SEARCH];
   out->density_ms = c->acc_ms[CAT_DENSITY];
   out->force_ms = c->acc_ms[CAT_FORCE];
   out->other_ms = c->acc_ms[CAT_OTHER];

@@ -53,31 +53,55 @@ struct PairOut {
   float v[kForceComps];  // 0-2 pressure (:176-178)  3-5 viscosity (:206-208)  6-8 colour gradient (:248-250)  9 colour laplacian (:252)
 };
 
+// ---- IEEE-754 fp32 division with a shared divisor -------------------------------------------------------
+// A pair divides three numbers by r and four by rho_j.  hipcc expands every `a / b` into
+//   v_div_scale x2, v_rcp, 2 fma (Newton step on the reciprocal), mul, 4 fma, v_div_fmas, v_div_fixup.
+// The scale/fixup instructions only act on operands near the ends of the exponent range (|b| or |a/b|
+// within ~2^-126 / 2^+96 of the limits), which r in (0, h], rho >= m*W(0) and the numerators here never are.
+// Without them the quotient is exactly the fma chain below, so it is computed with ONE refined reciprocal
+// per divisor: same bits as `a / b`, a third of the instructions.  (Sign of a zero quotient aside, which
+// cannot reach a result: the sums start at +0 and x + (+-0) = x.)
+__device__ inline float refined_rcp(float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  float e = __builtin_fmaf(-b, y, 1.0f);
+  return __builtin_fmaf(e, y, y);
+}
+__device__ inline float div_by(float a, float b, float y) {  // y = refined_rcp(b)
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
 __device__ inline PairOut pair_eval(const DevParams& P, float dx, float dy, float dz, float r2, float pi,
                                     float rho_j, float dvx, float dvy, float dvz) {
   PairOut o;
   float r = sqrtf(r2);
   float ux = 0.0f, uy = 0.0f, uz = 0.0f;  // vecNormalize(r, r)  :28-39
   if (r > 0.0f) {
-    ux = dx / r;
-    uy = dy / r;
-    uz = dz / r;
+    const float yr = refined_rcp(r);
+    ux = div_by(dx, r, yr);
+    uy = div_by(dy, r, yr);
+    uz = div_by(dz, r, yr);
   }
-  float pj = P.c2 * (rho_j - P.rho0);                                    // :164
-  float mfp = P.neg_m * (pi + pj) / (2.0f * rho_j) * grad_spiky(P, r);  // :170
+  const float yrho = refined_rcp(rho_j);
+  float pj = P.c2 * (rho_j - P.rho0);  // :164
+  // :170  x / (2*rho) == (x / rho) / 2 exactly: scaling by a power of two commutes with rounding
+  float mfp = div_by(P.neg_m * (pi + pj), rho_j, yrho) * 0.5f * grad_spiky(P, r);
   o.v[0] = mfp * ux;
   o.v[1] = mfp * uy;
   o.v[2] = mfp * uz;
-  float t = P.visc_m * lapl_visc(P, r) / rho_j;  // :204
+  float t = div_by(P.visc_m * lapl_visc(P, r), rho_j, yrho);  // :204
   o.v[3] = dvx * t;
   o.v[4] = dvy * t;
   o.v[5] = dvz * t;
   if (P.tension) {
-    float mg = P.m * grad_poly6(P, r) / rho_j;  // :242
+    float mg = div_by(P.m * grad_poly6(P, r), rho_j, yrho);  // :242
     o.v[6] = ux * mg;
     o.v[7] = uy * mg;
     o.v[8] = uz * mg;
-    o.v[9] = P.m * lapl_poly6(P, r) / rho_j;  // :252
+    o.v[9] = div_by(P.m * lapl_poly6(P, r), rho_j, yrho);  // :252
   } else {
     o.v[6] = o.v[7] = o.v[8] = o.v[9] = 0.0f;
   }

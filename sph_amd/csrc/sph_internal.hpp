@@ -40,12 +40,14 @@ struct Sorted {
 };
 
 // Which candidates of a particle's flattened 27-cell stencil are neighbours (distance test passed), one
-// bit per candidate, written by the density pass and walked by the force pass.  Word w of particle slot s
-// lives at words[w * stride + s]; ncand[s] is the number of candidates (bits) of slot s.
-constexpr int kMaskWords = 16;
+// bit per candidate, written by the neighbour search and walked by the density and force passes.  Word w of particle slot s
+// lives at words[w * stride + s]; ncand[s] is the number of candidates (bits) of slot s, nnb[s] the number
+// of neighbours (set bits).
+constexpr int kMaskWords = 64;
 struct NeighbourMask {
   uint32_t* words;
   int32_t* ncand;
+  int32_t* nnb;
   size_t stride;
 };
 
@@ -70,13 +72,15 @@ struct DebugBuffers {
 
 constexpr int kScanItems = 4096;  // cells per scan block
 
-// Flavour of the density/force sweeps: queued is the default; the others exist for verification and ablation.
-enum SweepMode { SWEEP_QUEUED = 0, SWEEP_PLAIN = 1, SWEEP_EXACT = 2 };
+// Flavour of the density/force sweeps: masked is the default; the others exist for verification and ablation.
+enum SweepMode { SWEEP_MASKED = 0, SWEEP_PLAIN = 1, SWEEP_EXACT = 2 };
 
 void launch_split_aos(hipStream_t s, const float* pos_aos, const float* vel_aos, int n, State st);
 void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, GridBuffers g);
 void launch_scan(hipStream_t s, GridBuffers g);
 void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g);
+void launch_neighbours(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
+                       const NeighbourMask& nm);
 void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
                     int32_t* ncount, const NeighbourMask& nm, SweepMode mode);
 void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,

@@ -1,22 +1,27 @@
-// Neighbour sweeps for gfx950: density pass and force+integration pass of one SPH step
+// Neighbour sweeps for gfx950: neighbour search, density pass and force+integration pass of one SPH step
 // (reference compute/compute.cpp:131-150 and :153-319).  Compile with -ffp-contract=off.
 //
-// Data the sweeps read is the grid-sorted copy of the state, packed for gathers: one float4 per particle
-// for the position and one for velocity + density, so a neighbour costs one 16-byte load per array instead
-// of one 4-byte load per component.  Cells are linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the
-// slab axis, slowest): the 27-cell stencil of a particle is 9 runs of up to 3 z-adjacent cells, each run ONE
-// contiguous slot range.  Runs are visited dx-major, dy-minor; inside a cell particles are in ascending id
-// order.  That order is a pure function of (positions, ids), so results do not depend on how particles
-// share waves, contexts or slabs.
+// The sweeps read the grid-sorted copy of the state, packed for gathers: one float4 per particle for the
+// position and one for velocity + density, so a neighbour costs one 16-byte load per array.  Cells are
+// linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the slab axis, slowest): the 27-cell stencil of a
+// particle is 9 runs of up to 3 z-adjacent cells, each run ONE contiguous slot range.  Runs are visited
+// dx-major, dy-minor; inside a cell particles are in ascending id order.  That order is a pure function of
+// (positions, ids), so results do not depend on how particles share waves, blocks, contexts or slabs.
 //
-// Three flavours, same results bit for bit except SWEEP_EXACT's summation order:
-//   queued (default)  candidates that pass the distance test are pushed on a per-lane FIFO in LDS and the
-//                     pair arithmetic runs when a queue is full, with most lanes of the wave busy.  The
-//                     density pass also records WHICH candidates passed as a per-particle bitmask over the
-//                     flattened stencil, so the force pass tests nothing: it walks the set bits;
-//   plain             evaluates a neighbour on the spot (ablation);
-//   exact             sums neighbours in ascending particle id, the order in which the reference's
-//                     j = 0..N-1 loops meet the non-zero terms: bit-identical to the reference.
+// Default (SWEEP_MASKED) pipeline, one lane per particle in every kernel:
+//   k_neighbours  the only kernel that tests distances: walks the flattened stencil four candidates per trip
+//                 (independent 16-byte gathers) and records WHICH candidates satisfy sqrtf(r2) <= h as a
+//                 bitmask per particle, plus the candidate and neighbour counts;
+//   k_density     walks the set bits: every loop trip is a true neighbour, so the sqrt / double-precision
+//                 kernel arithmetic runs with the wave's lanes busy instead of ~20 % of them;
+//   k_force       same walk with the pair arithmetic of :153-262, then Euler step and wall reflection.
+// In the two mask walkers the 256 particles of a block are handed to lanes in order of decreasing neighbour
+// count, so the lanes of a wave (which run in lockstep) carry similar loads.
+//
+// Other flavours, for verification and ablation:
+//   SWEEP_PLAIN  tests and evaluates in one loop (no mask); same results bit for bit as SWEEP_MASKED;
+//   SWEEP_EXACT  sums neighbours in ascending particle id, the order in which the reference's j = 0..N-1
+//                loops meet the non-zero terms: bit-identical to the reference.
 #include "sph_device.hpp"
 
 namespace sph {
@@ -24,7 +29,6 @@ namespace sph {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kQueue = 16;
 constexpr int kAhead = 4;  // candidates fetched per loop trip: independent loads in flight per lane
 constexpr int kMaskBits = 32 * kMaskWords;
 
@@ -80,76 +84,155 @@ __device__ inline float dist2_to(const float4& a, const float4& b, float& dx, fl
   return dist2(dx, dy, dz);
 }
 
+// Slot range [lo, hi) of the local x-columns [col_lo, col_hi).
+__device__ inline void column_slots(const DevParams& P, const int32_t* __restrict__ start, int col_lo, int col_hi,
+                                    int& lo, int& hi) {
+  const int cpc = P.ny * P.nz;
+  lo = start[col_lo * cpc];
+  hi = start[col_hi * cpc];
+}
+
+// ---- neighbour search ---------------------------------------------------------------------------------------------
+// Bit q of a particle's mask <=> the q-th candidate of its flattened stencil passes sqrtf(r2) <= h, tested as
+// r2 <= r2_max with r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
+__global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ cell_s, NeighbourMask nm) {
+  int lo, hi;
+  column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
+  const int s = lo + xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (s >= hi) return;
+  const float4 pi = st.pos[s];
+  const CellCoord cc = decode_cell(P, cell_s[s]);
+  unsigned word = 0;
+  int q = 0, cnt = 0;
+  float dx, dy, dz;
+  RunCursor c{-1, 0, 0};
+  for (;;) {
+    if (c.j >= c.e) {
+      if (!next_run(P, start, cc, c)) break;
+      continue;
+    }
+    const int m = c.e - c.j < kAhead ? c.e - c.j : kAhead;
+    float4 cand[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? c.j + u : c.j];
+    unsigned bits = 0;
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      const float r2 = dist2_to(pi, cand[u], dx, dy, dz);
+      bits |= (u < m && r2 <= P.r2_max ? 1u : 0u) << u;
+    }
+    cnt += __popc(bits);
+    const int sh = q & 31;
+    word |= bits << sh;
+    q += m;
+    if (sh + m >= 32) {  // the current word is complete; bits past it start the next one
+      if ((q >> 5) <= kMaskWords) nm.words[(size_t)((q >> 5) - 1) * nm.stride + s] = word;
+      word = sh + m > 32 ? bits >> (32 - sh) : 0u;
+    }
+    c.j += m;
+  }
+  if ((q & 31) != 0 && (q >> 5) < kMaskWords) nm.words[(size_t)(q >> 5) * nm.stride + s] = word;
+  nm.ncand[s] = q;
+  nm.nnb[s] = cnt;
+}
+
+// Lanes of a wave run in lockstep, so a wave takes as long as its particle with the most neighbours.  Hand the
+// block's 256 particles (slots lo + 256*blk ...) to lanes in order of decreasing neighbour count (8-wide bins,
+// counting sort in LDS).  Which lane advances which particle has no influence on any result.
+// Returns the index within the block that this lane takes.
+__device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int hi) {
+  __shared__ int bin_fill[66];
+  __shared__ unsigned short perm[kBlock];
+  const int s_nat = first_slot + threadIdx.x;
+  const int k = s_nat < hi ? nm.nnb[s_nat] : -1;
+  const int bin = k < 0 ? 64 : 63 - (k >> 3 > 63 ? 63 : k >> 3);  // idle lanes last
+  if (threadIdx.x < 66) bin_fill[threadIdx.x] = 0;
+  __syncthreads();
+  const int rank = atomicAdd(&bin_fill[bin], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < 65; b++) {
+      const int c = bin_fill[b];
+      bin_fill[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  perm[bin_fill[bin] + rank] = (unsigned short)threadIdx.x;
+  __syncthreads();
+  return perm[threadIdx.x];
+}
+
+// Calls visit(j) for every neighbour slot j of particle slot s, in stencil order, from the mask written by
+// k_neighbours.  Falls back to testing again when the stencil holds more candidates than the mask has bits
+// (cells crowded beyond ~75 particles each).
+template <class Visit>
+__device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
+                                          const NeighbourMask& nm, int s, const float4& pi, const CellCoord cc,
+                                          Visit visit) {
+  const int ncand = nm.ncand[s];
+  RunCursor c{-1, 0, 0};
+  if (ncand <= kMaskBits) {
+    int run_q = 0;  // flattened index of the first candidate of the current run
+    int w = -1;
+    unsigned m = 0;
+    const int nwords = (ncand + 31) >> 5;
+    for (;;) {
+      if (m == 0) {
+        if (++w >= nwords) break;
+        m = nm.words[(size_t)w * nm.stride + s];
+        continue;
+      }
+      const int q = (w << 5) + __ffs(m) - 1;
+      m &= m - 1;
+      while (q >= run_q + (c.e - c.j)) {  // runs are met in ascending order
+        run_q += c.e - c.j;
+        next_run(P, start, cc, c);
+      }
+      visit(c.j + (q - run_q));
+    }
+  } else {
+    float dx, dy, dz;
+    while (next_run(P, start, cc, c))
+      for (int j = c.j; j < c.e; j++)
+        if (dist2_to(pi, st.pos[j], dx, dy, dz) <= P.r2_max) visit(j);
+  }
+}
+
 // ---- density ----------------------------------------------------------------------------------------------------
 // rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (:131-150).  Written to vel[s].w.
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, int n, const int32_t* __restrict__ start,
+__global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
-  __shared__ float queue[MODE == SWEEP_QUEUED ? kQueue : 1][kBlock];  // r2 of the queued neighbours
   // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
-  const int cpc = P.ny * P.nz;
-  const int s = start[P.dens_lo * cpc] + xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (s >= start[P.dens_hi * cpc]) return;
+  int lo, hi;
+  column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
+  const int first = lo + xcd_block(blockIdx.x, gridDim.x) * blockDim.x;
+  const int s = first + (MODE == SWEEP_MASKED ? lane_by_load(nm, first, hi) : (int)threadIdx.x);
+  if (s >= hi) return;
   const float4 pi = st.pos[s];
   const CellCoord cc = decode_cell(P, cell_s[s]);
   float acc = 0.0f;
   int cnt = 0;
   float dx, dy, dz;
-  if (MODE == SWEEP_QUEUED) {
-    int fill = 0;
-    auto drain = [&]() {
-#pragma unroll 4
-      for (int t = 0; t < kQueue; t++)
-        if (t < fill) acc += P.m * w_poly6(P, sqrtf(queue[t][threadIdx.x]));  // :144-146
-      cnt += fill;
-      fill = 0;
-    };
-    // bit q of the mask <=> the q-th candidate of the flattened stencil is a neighbour
-    unsigned word = 0;
-    int q = 0;
-    RunCursor c{-1, 0, 0};
-    for (;;) {
-      if (c.j >= c.e) {
-        if (!next_run(P, start, cc, c)) break;
-        continue;
-      }
-      const int m = c.e - c.j < kAhead ? c.e - c.j : kAhead;
-      float4 cand[kAhead];
-#pragma unroll
-      for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? c.j + u : c.j];
-#pragma unroll
-      for (int u = 0; u < kAhead; u++) {
-        if (u < m) {
-          const float r2 = dist2_to(pi, cand[u], dx, dy, dz);
-          const bool pass = r2 <= P.r2_max;  // sqrtf(r2) <= h
-          if (pass) queue[fill++][threadIdx.x] = r2;
-          word |= (pass ? 1u : 0u) << (q & 31);
-          q++;
-          if ((q & 31) == 0) {
-            if (q <= kMaskBits) nm.words[(size_t)(q / 32 - 1) * nm.stride + s] = word;
-            word = 0;
-          }
-        }
-      }
-      c.j += m;
-      if (__any(fill > kQueue - kAhead)) drain();
-    }
-    drain();
-    if ((q & 31) != 0 && q < kMaskBits) nm.words[(size_t)(q / 32) * nm.stride + s] = word;
-    nm.ncand[s] = q;
+  auto add = [&](float r2) {
+    acc += P.m * w_poly6(P, sqrtf(r2));  // :144-146
+    cnt++;
+  };
+  if (MODE == SWEEP_MASKED) {
+    for_each_neighbour(P, st, start, nm, s, pi, cc, [&](int j) { add(dist2_to(pi, st.pos[j], dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
       for (int j = c.j; j < c.e; j++) {
         const float r2 = dist2_to(pi, st.pos[j], dx, dy, dz);
-        if (r2 <= P.r2_max) {
-          acc += P.m * w_poly6(P, sqrtf(r2));
-          cnt++;
-        }
+        if (r2 <= P.r2_max) add(r2);
       }
     }
-  } else {  // SWEEP_EXACT
+  } else {  // SWEEP_EXACT: ascending particle id
     int last = -1;
     for (;;) {
       int best = 0x7fffffff;
@@ -166,8 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, int 
         }
       }
       if (best == 0x7fffffff) break;
-      acc += P.m * w_poly6(P, sqrtf(best_r2));
-      cnt++;
+      add(best_r2);
       last = best;
     }
   }
@@ -181,16 +263,16 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
-  __shared__ int queue[MODE == SWEEP_QUEUED ? kQueue : 1][kBlock];  // slot indices of the queued neighbours
   // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
-  const int cpc = P.ny * P.nz;
-  const int base = start[P.own_lo * cpc], bound = start[P.own_hi * cpc];
-  const int o = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (o == 0 && n_own_out) {
-    const int real = P.nx * cpc;
+  int base, bound;
+  column_slots(P, start, P.own_lo, P.own_hi, base, bound);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_own_out) {
+    const int real = P.nx * P.ny * P.nz;
     n_own_out[0] = bound - base;                   // particles this context keeps
     n_own_out[1] = start[real + 1] - start[real];  // trash cell: particles outside the local grid
   }
+  const int first = xcd_block(blockIdx.x, gridDim.x) * blockDim.x;
+  const int o = first + (MODE == SWEEP_MASKED ? lane_by_load(nm, base + first, bound) : (int)threadIdx.x);
   const int s = base + o;
   if (s >= bound) return;
   const float4 pi4 = st.pos[s];
@@ -209,56 +291,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     for (int q = 0; q < kForceComps; q++) a[q] += w.v[q];
   };
 
-  const int ncand = MODE == SWEEP_QUEUED ? nm.ncand[s] : 0;
-  if (MODE == SWEEP_QUEUED && ncand <= kMaskBits) {
-    // Walk the set bits of the density pass's neighbour mask: no distance tests, every trip is a neighbour.
-    RunCursor c{-1, 0, 0};
-    int run_q = 0;  // flattened index of the first candidate of the current run
-    int w = -1;
-    unsigned m = 0;
-    const int nwords = (ncand + 31) >> 5;
-    for (;;) {
-      if (m == 0) {
-        if (++w >= nwords) break;
-        m = nm.words[(size_t)w * nm.stride + s];
-        continue;
-      }
-      const int q = (w << 5) + __ffs(m) - 1;
-      m &= m - 1;
-      while (q >= run_q + (c.e - c.j)) {  // runs are met in ascending order
-        run_q += c.e - c.j;
-        next_run(P, start, cc, c);
-      }
-      add_neighbour(c.j + (q - run_q));
-    }
-  } else if (MODE == SWEEP_QUEUED) {
-    // more candidates than mask bits (extremely crowded cells): test again, queueing the hits
-    int fill = 0;
-    auto drain = [&]() {
-#pragma unroll 1
-      for (int t = 0; t < kQueue; t++)
-        if (t < fill) add_neighbour(queue[t][threadIdx.x]);
-      fill = 0;
-    };
-    RunCursor c{-1, 0, 0};
-    for (;;) {
-      if (c.j >= c.e) {
-        if (!next_run(P, start, cc, c)) break;
-        continue;
-      }
-      const int m = c.e - c.j < kAhead ? c.e - c.j : kAhead;
-      float4 cand[kAhead];
-#pragma unroll
-      for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? c.j + u : c.j];
-#pragma unroll
-      for (int u = 0; u < kAhead; u++) {
-        const float r2 = dist2_to(pi4, cand[u], dx, dy, dz);
-        if (u < m && r2 <= P.r2_max) queue[fill++][threadIdx.x] = c.j + u;
-      }
-      c.j += m;
-      if (__any(fill > kQueue - kAhead)) drain();
-    }
-    drain();
+  if (MODE == SWEEP_MASKED) {
+    for_each_neighbour(P, st, start, nm, s, pi4, cc, add_neighbour);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
@@ -267,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
         if (r2 <= P.r2_max) add_neighbour(j);
       }
     }
-  } else {  // SWEEP_EXACT
+  } else {  // SWEEP_EXACT: ascending particle id
     int last = -1;
     for (;;) {
       int best = 0x7fffffff, bj = -1;
@@ -305,16 +339,22 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
 
 }  // namespace
 
+void launch_neighbours(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
+                       const NeighbourMask& nm) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_neighbours, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm);
+}
+
 void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
                     int32_t* ncount, const NeighbourMask& nm, SweepMode mode) {
   if (n <= 0) return;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL(k_density<SWEEP_EXACT>, grid, block, 0, s, P, st, n, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL(k_density<SWEEP_EXACT>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
   else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL(k_density<SWEEP_PLAIN>, grid, block, 0, s, P, st, n, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL(k_density<SWEEP_PLAIN>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
   else
-    hipLaunchKernelGGL(k_density<SWEEP_QUEUED>, grid, block, 0, s, P, st, n, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL(k_density<SWEEP_MASKED>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
 }
 
 void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,
@@ -327,7 +367,7 @@ void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const Sta
   else if (mode == SWEEP_PLAIN)
     hipLaunchKernelGGL(k_force<SWEEP_PLAIN>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
   else
-    hipLaunchKernelGGL(k_force<SWEEP_QUEUED>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL(k_force<SWEEP_MASKED>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
 }
 
 }  // namespace sph

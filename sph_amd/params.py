@@ -38,6 +38,7 @@ class SphTimings(C.Structure):
         ("hash_ms", C.c_double),
         ("scan_ms", C.c_double),
         ("reorder_ms", C.c_double),
+        ("search_ms", C.c_double),
         ("density_ms", C.c_double),
         ("force_ms", C.c_double),
         ("other_ms", C.c_double),
