@@ -29,7 +29,7 @@ namespace sph {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kAhead = 4;  // candidates fetched per loop trip: independent loads in flight per lane
+constexpr int kAhead = 4;  // candidates fetched per loop trip of the search: independent loads in flight per lane
 constexpr int kMaskBits = 32 * kMaskWords;
 
 __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
@@ -77,6 +77,28 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
   return true;
 }
 
+// The 9 stencil runs of every lane's particle, fetched up front (18 independent loads, one latency) into a
+// per-lane column of LDS, so that stepping from run to run inside the sweeps is an LDS read instead of two
+// dependent global loads that would stall the whole wave each time one lane steps.
+struct RunTable {
+  int (*b)[kBlock];    // first slot of run k
+  int (*len)[kBlock];  // number of slots of run k
+};
+__device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
+                                 const RunTable& rt) {
+  const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
+    const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;  // rows beyond the grid are empty runs
+    const int row = inside ? (x * P.ny + y) * P.nz : 0;
+    const int b = start[row + z0];
+    const int e = start[row + z1 + 1];
+    rt.b[k][threadIdx.x] = b;
+    rt.len[k][threadIdx.x] = inside ? e - b : 0;
+  }
+}
+
 __device__ inline float dist2_to(const float4& a, const float4& b, float& dx, float& dy, float& dz) {
   dx = a.x - b.x;  // :140-142
   dy = a.y - b.y;
@@ -93,29 +115,34 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 }
 
 // ---- neighbour search ---------------------------------------------------------------------------------------------
-// Bit q of a particle's mask <=> the q-th candidate of its flattened stencil passes sqrtf(r2) <= h, tested as
-// r2 <= r2_max with r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
+// The only kernel that tests distances.  One lane per particle walks its flattened stencil four candidates per
+// trip (four independent 16-byte gathers in flight) and packs the outcomes into the particle's mask:
+// bit q <=> the q-th candidate passes sqrtf(r2) <= h, tested as r2 <= r2_max with
+// r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
 __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ cell_s, NeighbourMask nm) {
+  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
   const int s = lo + xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (s >= hi) return;
   const float4 pi = st.pos[s];
-  const CellCoord cc = decode_cell(P, cell_s[s]);
+  fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_b, rt_len});
   unsigned word = 0;
   int q = 0, cnt = 0;
   float dx, dy, dz;
-  RunCursor c{-1, 0, 0};
+  int k = -1, j = 0, e = 0;  // current run, next slot, end of run
   for (;;) {
-    if (c.j >= c.e) {
-      if (!next_run(P, start, cc, c)) break;
+    if (j >= e) {
+      if (++k >= 9) break;
+      j = rt_b[k][threadIdx.x];
+      e = j + rt_len[k][threadIdx.x];
       continue;
     }
-    const int m = c.e - c.j < kAhead ? c.e - c.j : kAhead;
+    const int m = e - j < kAhead ? e - j : kAhead;
     float4 cand[kAhead];
 #pragma unroll
-    for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? c.j + u : c.j];
+    for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? j + u : j];
     unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < kAhead; u++) {
@@ -130,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
       if ((q >> 5) <= kMaskWords) nm.words[(size_t)((q >> 5) - 1) * nm.stride + s] = word;
       word = sh + m > 32 ? bits >> (32 - sh) : 0u;
     }
-    c.j += m;
+    j += m;
   }
   if ((q & 31) != 0 && (q >> 5) < kMaskWords) nm.words[(size_t)(q >> 5) * nm.stride + s] = word;
   nm.ncand[s] = q;
@@ -165,39 +192,61 @@ __device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int 
   return perm[threadIdx.x];
 }
 
-// Calls visit(j) for every neighbour slot j of particle slot s, in stencil order, from the mask written by
-// k_neighbours.  Falls back to testing again when the stencil holds more candidates than the mask has bits
-// (cells crowded beyond ~75 particles each).
-template <class Visit>
+// Calls visit(pos_j, vel_j) for every neighbour of particle slot s, in stencil order, from the mask written by
+// k_neighbours.  The loads of the NEXT neighbour are issued before the current one is evaluated, so their
+// latency hides behind the pair arithmetic.  Falls back to testing again when the stencil holds more
+// candidates than the mask has bits (cells crowded beyond ~75 particles each).
+template <bool WITH_VEL, class Visit>
 __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
                                           const NeighbourMask& nm, int s, const float4& pi, const CellCoord cc,
-                                          Visit visit) {
+                                          const RunTable& rt, Visit visit) {
   const int ncand = nm.ncand[s];
-  RunCursor c{-1, 0, 0};
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  fill_runs(P, start, cc, rt);
   if (ncand <= kMaskBits) {
-    int run_q = 0;  // flattened index of the first candidate of the current run
-    int w = -1;
-    unsigned m = 0;
     const int nwords = (ncand + 31) >> 5;
-    for (;;) {
-      if (m == 0) {
-        if (++w >= nwords) break;
-        m = nm.words[(size_t)w * nm.stride + s];
-        continue;
+    int k = 0;  // current run
+    int run_q = 0, run_b = rt.b[0][threadIdx.x], run_len = rt.len[0][threadIdx.x];
+    int w = 0;
+    unsigned m = nwords > 0 ? nm.words[s] : 0u;
+    unsigned m_next = nwords > 1 ? nm.words[nm.stride + s] : 0u;  // one word ahead
+    auto next_slot = [&]() -> int {  // slot of the next set bit, -1 when the mask is exhausted
+      while (m == 0) {
+        if (++w >= nwords) return -1;
+        m = m_next;
+        m_next = w + 1 < nwords ? nm.words[(size_t)(w + 1) * nm.stride + s] : 0u;
       }
       const int q = (w << 5) + __ffs(m) - 1;
       m &= m - 1;
-      while (q >= run_q + (c.e - c.j)) {  // runs are met in ascending order
-        run_q += c.e - c.j;
-        next_run(P, start, cc, c);
+      while (q >= run_q + run_len) {  // runs are met in ascending order
+        run_q += run_len;
+        ++k;
+        run_b = rt.b[k][threadIdx.x];
+        run_len = rt.len[k][threadIdx.x];
       }
-      visit(c.j + (q - run_q));
+      return run_b + (q - run_q);
+    };
+    int j = next_slot();
+    float4 pj = j >= 0 ? st.pos[j] : zero;
+    float4 vj = WITH_VEL && j >= 0 ? st.vel[j] : zero;
+    while (j >= 0) {
+      const int jn = next_slot();
+      const float4 pn = jn >= 0 ? st.pos[jn] : zero;
+      const float4 vn = WITH_VEL && jn >= 0 ? st.vel[jn] : zero;
+      visit(pj, vj);
+      j = jn;
+      pj = pn;
+      vj = vn;
     }
   } else {
     float dx, dy, dz;
-    while (next_run(P, start, cc, c))
-      for (int j = c.j; j < c.e; j++)
-        if (dist2_to(pi, st.pos[j], dx, dy, dz) <= P.r2_max) visit(j);
+    for (int k = 0; k < 9; k++) {
+      const int b = rt.b[k][threadIdx.x], e = b + rt.len[k][threadIdx.x];
+      for (int j = b; j < e; j++) {
+        const float4 pj = st.pos[j];
+        if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.vel[j] : zero);
+      }
+    }
   }
 }
 
@@ -207,6 +256,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
+  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];  // used by the masked flavour only
   // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
@@ -223,7 +273,8 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour(P, st, start, nm, s, pi, cc, [&](int j) { add(dist2_to(pi, st.pos[j], dx, dy, dz)); });
+    for_each_neighbour<false>(P, st, start, nm, s, pi, cc, RunTable{rt_b, rt_len},
+                              [&](const float4& pj, const float4&) { add(dist2_to(pi, pj, dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
@@ -263,6 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
+  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];  // used by the masked flavour only
   // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
   int base, bound;
   column_slots(P, start, P.own_lo, P.own_hi, base, bound);
@@ -283,22 +335,21 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   float a[kForceComps] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float dx, dy, dz;
 
-  auto add_neighbour = [&](int j) {
-    const float r2 = dist2_to(pi4, st.pos[j], dx, dy, dz);
-    const float4 vj = st.vel[j];
+  auto add_pair = [&](const float4& pj, const float4& vj) {
+    const float r2 = dist2_to(pi4, pj, dx, dy, dz);
     const PairOut w = pair_eval(P, dx, dy, dz, r2, pi, vj.w, vj.x - vi4.x, vj.y - vi4.y, vj.z - vi4.z);
 #pragma unroll
     for (int q = 0; q < kForceComps; q++) a[q] += w.v[q];
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour(P, st, start, nm, s, pi4, cc, add_neighbour);
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, cc, RunTable{rt_b, rt_len}, add_pair);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
       for (int j = c.j; j < c.e; j++) {
         const float r2 = dist2_to(pi4, st.pos[j], dx, dy, dz);
-        if (r2 <= P.r2_max) add_neighbour(j);
+        if (r2 <= P.r2_max) add_pair(st.pos[j], st.vel[j]);
       }
     }
   } else {  // SWEEP_EXACT: ascending particle id
@@ -317,7 +368,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
         }
       }
       if (bj < 0) break;
-      add_neighbour(bj);
+      add_pair(st.pos[bj], st.vel[bj]);
       last = best;
     }
   }
