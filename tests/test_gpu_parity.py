@@ -206,6 +206,24 @@ def test_all_particles_in_one_cell(oracle):
     assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po)
 
 
+def test_stencil_larger_than_the_neighbour_mask(oracle):
+    """2600 particles in one cell: the stencil holds more candidates than the 2048-bit neighbour mask, so the
+    density and force passes take their re-test fallback.  Checked bit for bit against the grid twin (same
+    summation order) and within tolerance against the all-pairs oracle."""
+    rng = np.random.default_rng(11)
+    pos = (np.float32(0.105) + rng.random((2600, 3), dtype=np.float32) * np.float32(0.004)).astype(np.float32)
+    vel = ((rng.random((2600, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)).astype(np.float32)
+    p = default_params(flags=DBG)
+    po, vo = pos.copy(), vel.copy()
+    pa, va = pos.copy(), vel.copy()
+    (gp, gv), (rho, f, nc, cell) = run_gpu(p, pos, vel, 1)
+    rho_o, f_o, nc_o = oracle.step_grid(p, po, vo, order=0, want_debug=True)
+    assert len(np.unique(cell)) == 1 and np.array_equal(nc, nc_o) and nc.min() > 2048
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po) and bits_equal(gv, vo)
+    oracle.step_allpairs(p, pa, va)
+    assert max_rel(gp, pa) <= TOL_ONE_STEP
+
+
 def test_particles_outside_the_tank(oracle):
     """Positions beyond the walls are legal inputs for the reference (all-pairs); cell indices
     clamp, which only merges cells, so the stencil still covers every neighbour pair."""
