@@ -18,14 +18,18 @@ os.makedirs(dst, exist_ok=True)
 def short(name):
     return name.split("(anonymous namespace)::")[-1].split("(")[0].replace("void ", "")
 
-stats = glob.glob(os.path.join(src, f"prof_{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):
+    # gpurun merges every call's files into gpurun_out/, so earlier runs of the same tag linger: take the latest
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+stats = newest(os.path.join(src, f"prof_{tag}_stats", "**", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench_line = [l for l in open(os.path.join(src, f"prof_{tag}_stats.log")) if l.startswith("{")][-1]
 open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(bench_line)
 bench = json.loads(bench_line)
 
 def counters(kind):
-    f = glob.glob(os.path.join(src, f"prof_{tag}_{kind}", "**", "*counter_collection.csv"), recursive=True)[0]
+    f = newest(os.path.join(src, f"prof_{tag}_{kind}", "**", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "sph::" in r["Kernel_Name"]:
@@ -48,7 +52,7 @@ json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1
 json.dump(out, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(stats)))
 print(f"{tag}: bench under rocprof: {bench['value']:.3e} pu/s, {bench['ms_per_step']:.3f} ms/step")
-for r in rows[:8]:
+for r in rows[:10]:
     print("  %-22s calls %5s avg %9.1f us  %5.1f%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 print("  calibration k_hash read: %.1f MB corrected vs %.1f MB expected" % (hash_read / 1e6, 12.0 * n / 1e6))
 for k, v in out["kernels"].items():

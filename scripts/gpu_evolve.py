@@ -8,7 +8,9 @@ side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 pos, vel, p = scenes.dam_break(side)
 n = pos.shape[0]
+only = sys.argv[3] if len(sys.argv) > 3 else None
 for name, extra in (("masked", 0), ("lane", SPH_FLAG_LANE_SWEEP)):
+    if only and name != only: continue
     p.flags = SPH_FLAG_SURFACE_TENSION | extra
     sim = capi.Simulation(p, n_max=n); sim.upload(pos, vel); sim.enable_timing(True)
     for w in range(windows):

@@ -24,6 +24,7 @@ struct DevParams {
   int own_lo, own_hi;        // local x-columns this context integrates: [own_lo, own_hi)
   int dens_lo, dens_hi;      // local x-columns whose density is needed: own plus one ghost column per side
   int tension;               // surface-tension term on/off
+  int xcd_run;               // consecutive workgroups of a sweep that share an XCD (set by the sweep launchers)
 };
 
 // Structure-of-arrays particle state in HBM.
