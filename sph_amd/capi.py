@@ -12,7 +12,7 @@ import numpy as np
 from .params import (SPH_FLAG_EXACT_ORDER, SPH_FLAG_KEEP_DEBUG, SPH_FLAG_SURFACE_TENSION,  # noqa: F401
                      SphParams, SphTimings, default_params)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsph_amd.so")
+LIB_PATH = os.environ.get("SPH_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsph_amd.so")
 
 # Every symbol include/sph_amd.h declares: (name, restype, argtypes)
 _P = C.POINTER(SphParams)

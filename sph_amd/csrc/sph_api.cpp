@@ -333,7 +333,7 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
   const size_t n = (size_t)n_max;
-  if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n)) || (rc = dev_alloc(&c->sorted.vel, n)) ||
+  if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n)) || (rc = dev_alloc(&c->sorted.rec, n)) ||
       (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)kMaskWords * n)) ||
       (rc = dev_alloc(&c->nmask.ncand, n)) || (rc = dev_alloc(&c->nmask.nnb, n)))
     return bail(rc);
@@ -403,7 +403,7 @@ int sph_destroy(sph_context* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   free_state(&c->cur);
-  (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.vel); (void)hipFree(c->sorted.id);
+  (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.rec); (void)hipFree(c->sorted.id);
   (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand); (void)hipFree(c->nmask.nnb);
   (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.block_sums);
   (void)hipFree(c->grid.cell_of); (void)hipFree(c->grid.rank_of); (void)hipFree(c->grid.src_of);
@@ -513,7 +513,7 @@ int sph_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount
   float* d_force = d_rho + n;
   int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
   int32_t* d_cell = d_ncount + n;
-  launch_gather_debug(c->stream, c->cur.id, (int)n, c->sorted.vel, c->dbg.force, c->dbg.ncount, c->grid.cell_s,
+  launch_gather_debug(c->stream, c->cur.id, (int)n, c->sorted.rec, c->dbg.force, c->dbg.ncount, c->grid.cell_s,
                       rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
                       cell ? d_cell : nullptr);
   HIP_TRY(hipGetLastError());
@@ -665,7 +665,7 @@ int sph_slab_download_debug(sph_context* c, float* rho, float* force, int32_t* n
   int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
   int32_t* d_cell = d_ncount + n;
   // the force plane stride is the launch size of the step that wrote it: recover it from the step's n
-  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->sorted.vel, c->dbg.force, c->dbg.ncount,
+  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->sorted.rec, c->dbg.force, c->dbg.ncount,
                     c->grid.cell_s, rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
                     cell ? d_cell : nullptr);
   HIP_TRY(hipGetLastError());

@@ -33,10 +33,17 @@ struct State {
   int32_t* id;
 };
 
-// Grid-sorted working copy of the state, packed for neighbour gathers (one 16-byte load per array).
+// Grid-sorted working copy of the state, laid out for neighbour gathers.  The search and the density pass
+// read positions only: 16 bytes per candidate from `pos`.  The force pass needs everything about a neighbour:
+// `rec` holds position and velocity + density side by side, so one 128-byte line serves both loads (with two
+// separate arrays the pass fetched twice as many lines into L1, which bounds it where the fluid is compressed).
+struct ParticleRec {
+  float4 pos;  // x, y, z, unused
+  float4 vel;  // vx, vy, vz, density (w is written by the density pass)
+};
 struct Sorted {
-  float4* pos;  // x, y, z, unused
-  float4* vel;  // vx, vy, vz, density (w is written by the density pass)
+  float4* pos;
+  ParticleRec* rec;
   int32_t* id;
 };
 
@@ -94,10 +101,10 @@ void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, con
 void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
-                       const float4* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       const ParticleRec* rec_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
                        float* rho, float* force, int32_t* ncount, int32_t* cell);
 void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos);
-void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float4* rho_s,
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const ParticleRec* rec_s,
                          const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
                          float* rho, float* force, int32_t* ncount, int32_t* cell);
 

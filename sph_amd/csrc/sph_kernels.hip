@@ -46,13 +46,13 @@ __global__ void k_gather_aos(State st, int n, float* __restrict__ pos, float* __
   }
 }
 
-__global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const float4* velrho_s,
+__global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const ParticleRec* rec_s,
                                const float* force_s, const int32_t* ncount_s, const int32_t* cell_s,
                                float* rho, float* force, int32_t* ncount, int32_t* cell) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   int i = id[s];
-  if (rho) rho[i] = velrho_s[s].w;
+  if (rho) rho[i] = rec_s[s].vel.w;
   if (force) {
     force[3 * i + 0] = force_s[s];
     force[3 * i + 1] = force_s[(size_t)n + s];
@@ -215,8 +215,10 @@ __global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict
   int r = 0;
   for (int t = b; t < e; t++) r += id_prov[t] < my;
   int d = b + r;
-  out.pos[d] = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
-  out.vel[d] = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
+  const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
+  out.pos[d] = pos;
+  out.rec[d].pos = pos;
+  out.rec[d].vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
   out.id[d] = my;
   cell_s[d] = c;
 }
@@ -297,13 +299,13 @@ __global__ void k_join_aos(State st, int n, float* __restrict__ pos, float* __re
 // Intermediates of the last step for the own particles, in the order the new state was written
 // (index o <-> sorted slot base + o).
 __global__ void k_join_debug(DevParams P, const int32_t* __restrict__ start, int n_own, int n_stride,
-                             const float4* __restrict__ velrho_s, const float* __restrict__ force_o,
+                             const ParticleRec* __restrict__ rec_s, const float* __restrict__ force_o,
                              const int32_t* __restrict__ ncount_s, const int32_t* __restrict__ cell_s,
                              float* rho, float* force, int32_t* ncount, int32_t* cell) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n_own) return;
   int s = start[P.own_lo * P.ny * P.nz] + o;
-  if (rho) rho[o] = velrho_s[s].w;
+  if (rho) rho[o] = rec_s[s].vel.w;
   if (force) {
     force[3 * o + 0] = force_o[o];
     force[3 * o + 1] = force_o[(size_t)n_stride + o];
@@ -371,11 +373,11 @@ void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* v
 }
 
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
-                       const float4* rho_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
+                       const ParticleRec* rec_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
                        float* rho, float* force, int32_t* ncount, int32_t* cell) {
   if (n_own <= 0) return;
   hipLaunchKernelGGL(k_join_debug, dim3(div_up(n_own, kBlock)), dim3(kBlock), 0, s, P, start, n_own, n_stride,
-                     rho_s, force_o, ncount_s, cell_s, rho, force, ncount, cell);
+                     rec_s, force_o, ncount_s, cell_s, rho, force, ncount, cell);
 }
 
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out) {
@@ -387,11 +389,11 @@ void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, fl
   hipLaunchKernelGGL(k_gather_aos, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, st, n, pos_aos, vel_aos);
 }
 
-void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const float4* rho_s, const float* force_s,
+void launch_gather_debug(hipStream_t s, const int32_t* id, int n, const ParticleRec* rec_s, const float* force_s,
                          const int32_t* ncount_s, const int32_t* cell_s, float* rho, float* force,
                          int32_t* ncount, int32_t* cell) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_gather_debug, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, id, n, rho_s, force_s, ncount_s,
+  hipLaunchKernelGGL(k_gather_debug, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, id, n, rec_s, force_s, ncount_s,
                      cell_s, rho, force, ncount, cell);
 }
 

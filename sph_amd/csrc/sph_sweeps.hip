@@ -2,7 +2,7 @@
 // (reference compute/compute.cpp:131-150 and :153-319).  Compile with -ffp-contract=off.
 //
 // The sweeps read the grid-sorted copy of the state, packed for gathers: one float4 per particle for the
-// position and one for velocity + density, so a neighbour costs one 16-byte load per array.  Cells are
+// position (search, density) and a 32-byte record with position and velocity + density (force).  Cells are
 // linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the slab axis, slowest): the 27-cell stencil of a
 // particle is 9 runs of up to 3 z-adjacent cells, each run ONE contiguous slot range.  Runs are visited
 // dx-major, dy-minor; inside a cell particles are in ascending id order.  That order is a pure function of
@@ -28,7 +28,10 @@ namespace sph {
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef SPH_KBLOCK
+#define SPH_KBLOCK 256
+#endif
+constexpr int kBlock = SPH_KBLOCK;
 constexpr int kAhead = 4;  // candidates fetched per loop trip of the search: independent loads in flight per lane
 constexpr int kMaskBits = 32 * kMaskWords;
 
@@ -84,22 +87,32 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
 // The 9 stencil runs of every lane's particle, fetched up front (18 independent loads, one latency) into a
 // per-lane column of LDS, so that stepping from run to run inside the sweeps is an LDS read instead of two
 // dependent global loads that would stall the whole wave each time one lane steps.
-struct RunTable {
-  int (*b)[kBlock];    // first slot of run k
-  int (*len)[kBlock];  // number of slots of run k
+template <int W>
+struct RunTableW {
+  int (*b)[W];    // first slot of run k
+  int (*len)[W];  // number of slots of run k
 };
+using RunTable = RunTableW<kBlock>;
 __device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
                                  const RunTable& rt) {
   const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
+  // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
+  // no branch, so that all 18 loads are issued before the first is waited for
+  int b[9], e[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
-    const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;  // rows beyond the grid are empty runs
-    const int row = inside ? (x * P.ny + y) * P.nz : 0;
-    const int b = start[row + z0];
-    const int e = start[row + z1 + 1];
-    rt.b[k][threadIdx.x] = b;
-    rt.len[k][threadIdx.x] = inside ? e - b : 0;
+    const int xc = x < 0 ? 0 : (x > P.nx - 1 ? P.nx - 1 : x), yc = y < 0 ? 0 : (y > P.ny - 1 ? P.ny - 1 : y);
+    const int row = (xc * P.ny + yc) * P.nz;
+    b[k] = start[row + z0];
+    e[k] = start[row + z1 + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
+    const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
+    rt.b[k][threadIdx.x] = b[k];
+    rt.len[k][threadIdx.x] = inside ? e[k] - b[k] : 0;
   }
 }
 
@@ -172,91 +185,111 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
 // block's 256 particles (slots lo + 256*blk ...) to lanes in order of decreasing neighbour count (8-wide bins,
 // counting sort in LDS).  Which lane advances which particle has no influence on any result.
 // Returns the index within the block that this lane takes.
-__device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int hi) {
+__device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count, -1 for a lane without a particle
   __shared__ int bin_fill[66];
   __shared__ unsigned short perm[kBlock];
-  const int s_nat = first_slot + threadIdx.x;
-  const int k = s_nat < hi ? nm.nnb[s_nat] : -1;
   const int bin = k < 0 ? 64 : 63 - (k >> 3 > 63 ? 63 : k >> 3);  // idle lanes last
-  if (threadIdx.x < 66) bin_fill[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < 66; i += blockDim.x) bin_fill[i] = 0;
   __syncthreads();
   const int rank = atomicAdd(&bin_fill[bin], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int b = 0; b < 65; b++) {
-      const int c = bin_fill[b];
-      bin_fill[b] = run;
-      run += c;
+  if (threadIdx.x < 64) {  // first wave: exclusive prefix sum over bins 0..63, bin 64 (idle lanes) after them
+    const int c = bin_fill[threadIdx.x];
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if ((int)threadIdx.x >= d) incl += up;
     }
+    bin_fill[threadIdx.x] = incl - c;
+    if (threadIdx.x == 63) bin_fill[64] = incl;
   }
   __syncthreads();
   perm[bin_fill[bin] + rank] = (unsigned short)threadIdx.x;
   __syncthreads();
   return perm[threadIdx.x];
 }
+__device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int hi) {
+  const int s_nat = first_slot + threadIdx.x;
+  return lane_by_count(s_nat < hi ? nm.nnb[s_nat] : -1);
+}
+
+// Walks the set bits of particle slot s's candidate mask in order and calls visit(pos_j, vel_j) for each; load(j,
+// pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
+// of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
+// current one is evaluated, so their latency hides behind the pair arithmetic.
+template <class Table, class Load, class Visit>
+__device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, const Table& rt, int col, Load load,
+                                 Visit visit) {
+  const int nwords = (ncand + 31) >> 5;
+  int k = 0;  // current run
+  int run_q = 0, run_b = rt.b[0][col], run_len = rt.len[0][col];
+  int w = 0;
+  unsigned m = nwords > 0 ? nm.words[s] : 0u;
+  unsigned m_next = nwords > 1 ? nm.words[nm.stride + s] : 0u;  // one word ahead
+  auto next_index = [&]() -> int {  // index of the next set bit's candidate, -1 when the mask is exhausted
+    while (m == 0) {
+      if (++w >= nwords) return -1;
+      m = m_next;
+      m_next = w + 1 < nwords ? nm.words[(size_t)(w + 1) * nm.stride + s] : 0u;
+    }
+    const int q = (w << 5) + __ffs(m) - 1;
+    m &= m - 1;
+    while (q >= run_q + run_len) {  // runs are met in ascending order
+      run_q += run_len;
+      ++k;
+      run_b = rt.b[k][col];
+      run_len = rt.len[k][col];
+    }
+    return run_b + (q - run_q);
+  };
+  float4 pj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vj = pj, pn = pj, vn = pj;
+  int j = next_index();
+  if (j >= 0) load(j, pj, vj);
+  while (j >= 0) {
+    const int jn = next_index();
+    if (jn >= 0) load(jn, pn, vn);
+    visit(pj, vj);
+    j = jn;
+    pj = pn;
+    vj = vn;
+  }
+}
 
 // Calls visit(pos_j, vel_j) for every neighbour of particle slot s, in stencil order, from the mask written by
-// k_neighbours.  The loads of the NEXT neighbour are issued before the current one is evaluated, so their
-// latency hides behind the pair arithmetic.  Falls back to testing again when the stencil holds more
-// candidates than the mask has bits (cells crowded beyond ~75 particles each).
+// the neighbour search.  Falls back to testing again when the stencil holds more candidates than the mask has
+// bits (cells crowded beyond ~75 particles each) or the search left no mask.
 template <bool WITH_VEL, class Visit>
 __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
                                           const NeighbourMask& nm, int s, const float4& pi, const CellCoord cc,
                                           const RunTable& rt, Visit visit) {
   const int ncand = nm.ncand[s];
-#define zero make_float4(0.0f, 0.0f, 0.0f, 0.0f)
   fill_runs(P, start, cc, rt);
   if (ncand <= kMaskBits) {
-    const int nwords = (ncand + 31) >> 5;
-    int k = 0;  // current run
-    int run_q = 0, run_b = rt.b[0][threadIdx.x], run_len = rt.len[0][threadIdx.x];
-    int w = 0;
-    unsigned m = nwords > 0 ? nm.words[s] : 0u;
-    unsigned m_next = nwords > 1 ? nm.words[nm.stride + s] : 0u;  // one word ahead
-    auto next_slot = [&]() -> int {  // slot of the next set bit, -1 when the mask is exhausted
-      while (m == 0) {
-        if (++w >= nwords) return -1;
-        m = m_next;
-        m_next = w + 1 < nwords ? nm.words[(size_t)(w + 1) * nm.stride + s] : 0u;
-      }
-      const int q = (w << 5) + __ffs(m) - 1;
-      m &= m - 1;
-      while (q >= run_q + run_len) {  // runs are met in ascending order
-        run_q += run_len;
-        ++k;
-        run_b = rt.b[k][threadIdx.x];
-        run_len = rt.len[k][threadIdx.x];
-      }
-      return run_b + (q - run_q);
-    };
-    int j = next_slot();
-    float4 pj = j >= 0 ? st.pos[j] : zero;
-    float4 vj = WITH_VEL && j >= 0 ? st.vel[j] : zero;
-    while (j >= 0) {
-      const int jn = next_slot();
-      const float4 pn = jn >= 0 ? st.pos[jn] : zero;
-      const float4 vn = WITH_VEL && jn >= 0 ? st.vel[jn] : zero;
-      visit(pj, vj);
-      j = jn;
-      pj = pn;
-      vj = vn;
-    }
+    walk_mask(nm, s, ncand, rt, threadIdx.x,
+              [&](int j, float4& pj, float4& vj) {
+                if (WITH_VEL) {
+                  pj = st.rec[j].pos;
+                  vj = st.rec[j].vel;
+                } else {
+                  pj = st.pos[j];
+                }
+              },
+              visit);
   } else {
     float dx, dy, dz;
     for (int k = 0; k < 9; k++) {
       const int b = rt.b[k][threadIdx.x], e = b + rt.len[k][threadIdx.x];
       for (int j = b; j < e; j++) {
         const float4 pj = st.pos[j];
-        if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.vel[j] : zero);
+        if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.rec[j].vel : pj);
       }
     }
   }
-#undef zero
 }
 
 // ---- density ----------------------------------------------------------------------------------------------------
-// rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (:131-150).  Written to vel[s].w.
+// rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (:131-150).  Written to rec[s].vel.w.
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s,
@@ -309,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
       last = best;
     }
   }
-  st.vel[s].w = acc;
+  st.rec[s].vel.w = acc;
   if (ncount) ncount[s] = cnt;
 }
 
@@ -333,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   const int s = base + o;
   if (s >= bound) return;
   const float4 pi4 = st.pos[s];
-  const float4 vi4 = st.vel[s];  // w = density
+  const float4 vi4 = st.rec[s].vel;  // w = density
   const float rho_i = vi4.w;
   const float pi = P.c2 * (rho_i - P.rho0);  // :158
   const CellCoord cc = decode_cell(P, cell_s[s]);
@@ -354,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     while (next_run(P, start, cc, c)) {
       for (int j = c.j; j < c.e; j++) {
         const float r2 = dist2_to(pi4, st.pos[j], dx, dy, dz);
-        if (r2 <= P.r2_max) add_pair(st.pos[j], st.vel[j]);
+        if (r2 <= P.r2_max) add_pair(st.pos[j], st.rec[j].vel);
       }
     }
   } else {  // SWEEP_EXACT: ascending particle id
@@ -373,7 +406,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
         }
       }
       if (bj < 0) break;
-      add_pair(st.pos[bj], st.vel[bj]);
+      add_pair(st.pos[bj], st.rec[bj].vel);
       last = best;
     }
   }
