@@ -63,18 +63,37 @@ __global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const Part
 }
 
 // ---- hash + histogram ---------------------------------------------------------------------------------
-__global__ void k_hash(DevParams P, State in, int n, int32_t* __restrict__ cell_of,
-                       int32_t* __restrict__ rank_of, int32_t* __restrict__ count) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  // A particle whose x-column lies outside this context's local grid (possible only in slab mode) goes to
-  // the trash cell appended after the last real cell: it sorts behind everything and no pass visits it.
-  int cx = cell_coord(in.x[i], P.cell, P.gnx) - P.cx_off;
-  int cy = cell_coord(in.y[i], P.cell, P.ny);
-  int cz = cell_coord(in.z[i], P.cell, P.nz);
-  int c = (cx < 0 || cx >= P.nx) ? P.nx * P.ny * P.nz : (cx * P.ny + cy) * P.nz + cz;
-  cell_of[i] = c;
-  rank_of[i] = atomicAdd(&count[c], 1);
+// The state arrives in the previous step's cell order, so neighbouring lanes mostly hash to the same cell: a run
+// of equal cells inside a wave takes ONE atomic (by its first lane, for the whole run) instead of one per lane.
+// The ranks are provisional either way; k_reorder replaces them by the rank of the id within the cell.
+__global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, int32_t* __restrict__ cell_of,
+                                                 int32_t* __restrict__ rank_of, int32_t* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool valid = i < n;
+  int c = -1 - lane;  // lanes without a particle: distinct keys, no atomics
+  if (valid) {
+    // A particle whose x-column lies outside this context's local grid (possible only in slab mode) goes to
+    // the trash cell appended after the last real cell: it sorts behind everything and no pass visits it.
+    const int cx = cell_coord(in.x[i], P.cell, P.gnx) - P.cx_off;
+    const int cy = cell_coord(in.y[i], P.cell, P.ny);
+    const int cz = cell_coord(in.z[i], P.cell, P.nz);
+    c = (cx < 0 || cx >= P.nx) ? P.nx * P.ny * P.nz : (cx * P.ny + cy) * P.nz + cz;
+  }
+  const int prev = __shfl_up(c, 1, 64);
+  const bool head = lane == 0 || prev != c;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long upto = (2ull << lane) - 1ull;  // bits 0..lane (all 64 for lane 63)
+  const int head_lane = 63 - __clzll((long long)(heads & upto));
+  const unsigned long long above = heads & ~upto;
+  const int next_head = above ? __ffsll((long long)above) - 1 : 64;
+  int base = 0;
+  if (head && valid) base = atomicAdd(&count[c], next_head - head_lane);
+  base = __shfl(base, head_lane, 64);
+  if (valid) {
+    cell_of[i] = c;
+    rank_of[i] = base + lane - head_lane;
+  }
 }
 
 // ---- exclusive scan over the cell histogram -----------------------------------------------------------

@@ -86,13 +86,13 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
 
 // The 9 stencil runs of every lane's particle, fetched up front (18 independent loads, one latency) into a
 // per-lane column of LDS, so that stepping from run to run inside the sweeps is an LDS read instead of two
-// dependent global loads that would stall the whole wave each time one lane steps.
-template <int W>
-struct RunTableW {
-  int (*b)[W];    // first slot of run k
-  int (*len)[W];  // number of slots of run k
+// dependent global loads that would stall the whole wave each time one lane steps.  A run is stored by where it
+// sits in the particle's flattened candidate sequence: candidates [qend[k-1], qend[k]) are run k, and candidate q
+// of run k is sorted slot shift[k] + q.
+struct RunTable {
+  int (*shift)[kBlock];  // first slot of run k minus the number of candidates before run k
+  int (*qend)[kBlock];   // number of candidates up to and including run k
 };
-using RunTable = RunTableW<kBlock>;
 __device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
                                  const RunTable& rt) {
   const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
@@ -107,12 +107,14 @@ __device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__
     b[k] = start[row + z0];
     e[k] = start[row + z1 + 1];
   }
+  int q = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
     const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
-    rt.b[k][threadIdx.x] = b[k];
-    rt.len[k][threadIdx.x] = inside ? e[k] - b[k] : 0;
+    rt.shift[k][threadIdx.x] = b[k] - q;
+    q += inside ? e[k] - b[k] : 0;
+    rt.qend[k][threadIdx.x] = q;
   }
 }
 
@@ -138,25 +140,26 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 // r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
 __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ cell_s, NeighbourMask nm) {
-  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];
+  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
   const int s = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x + threadIdx.x;
   if (s >= hi) return;
   const float4 pi = st.pos[s];
-  fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_b, rt_len});
+  fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
   unsigned word = 0;
-  int q = 0, cnt = 0;
+  int q = 0, cnt = 0;  // q: candidates seen so far = index of the next one in the flattened stencil
   float dx, dy, dz;
-  int k = -1, j = 0, e = 0;  // current run, next slot, end of run
+  int k = -1, shift = 0, qe = 0;  // current run, its slot shift, its end in q
   for (;;) {
-    if (j >= e) {
+    if (q >= qe) {
       if (++k >= 9) break;
-      j = rt_b[k][threadIdx.x];
-      e = j + rt_len[k][threadIdx.x];
+      shift = rt_shift[k][threadIdx.x];
+      qe = rt_qend[k][threadIdx.x];
       continue;
     }
-    const int m = e - j < kAhead ? e - j : kAhead;
+    const int m = qe - q < kAhead ? qe - q : kAhead;
+    const int j = shift + q;
     float4 cand[kAhead];
 #pragma unroll
     for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? j + u : j];
@@ -174,7 +177,6 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
       if ((q >> 5) <= kMaskWords) nm.words[(size_t)((q >> 5) - 1) * nm.stride + s] = word;
       word = sh + m > 32 ? bits >> (32 - sh) : 0u;
     }
-    j += m;
   }
   if ((q & 31) != 0 && (q >> 5) < kMaskWords) nm.words[(size_t)(q >> 5) * nm.stride + s] = word;
   nm.ncand[s] = q;
@@ -218,30 +220,38 @@ __device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int 
 // pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
 // of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
 // current one is evaluated, so their latency hides behind the pair arithmetic.
-template <class Table, class Load, class Visit>
-__device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, const Table& rt, int col, Load load,
+template <class Load, class Visit>
+__device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, const RunTable& rt, int col, Load load,
                                  Visit visit) {
-  const int nwords = (ncand + 31) >> 5;
-  int k = 0;  // current run
-  int run_q = 0, run_b = rt.b[0][col], run_len = rt.len[0][col];
-  int w = 0;
-  unsigned m = nwords > 0 ? nm.words[s] : 0u;
-  unsigned m_next = nwords > 1 ? nm.words[nm.stride + s] : 0u;  // one word ahead
+  int words_left = (ncand + 31) >> 5;  // words not yet taken into m
+  const uint32_t* wp = nm.words + s;   // word after the one in m
+  const size_t stride = nm.stride;
+  unsigned m = 0, m_next = 0;          // current word (bits still to visit), the word after it
+  if (words_left > 0) {
+    m = *wp;
+    wp += stride;
+    --words_left;
+  }
+  if (words_left > 0) m_next = *wp;
+  int qbase = 0;  // candidate index of bit 0 of the current word
+  int k = 0, shift = rt.shift[0][col], qe = rt.qend[0][col];  // current run
   auto next_index = [&]() -> int {  // index of the next set bit's candidate, -1 when the mask is exhausted
     while (m == 0) {
-      if (++w >= nwords) return -1;
+      if (words_left <= 0) return -1;
+      --words_left;
+      qbase += 32;
       m = m_next;
-      m_next = w + 1 < nwords ? nm.words[(size_t)(w + 1) * nm.stride + s] : 0u;
+      wp += stride;
+      m_next = words_left > 0 ? *wp : 0u;
     }
-    const int q = (w << 5) + __ffs(m) - 1;
+    const int q = qbase + __ffs(m) - 1;
     m &= m - 1;
-    while (q >= run_q + run_len) {  // runs are met in ascending order
-      run_q += run_len;
+    while (q >= qe) {  // runs are met in ascending order
       ++k;
-      run_b = rt.b[k][col];
-      run_len = rt.len[k][col];
+      shift = rt.shift[k][col];
+      qe = rt.qend[k][col];
     }
-    return run_b + (q - run_q);
+    return shift + q;
   };
   float4 pj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vj = pj, pn = pj, vn = pj;
   int j = next_index();
@@ -278,8 +288,9 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
               visit);
   } else {
     float dx, dy, dz;
-    for (int k = 0; k < 9; k++) {
-      const int b = rt.b[k][threadIdx.x], e = b + rt.len[k][threadIdx.x];
+    for (int k = 0, q = 0; k < 9; k++) {
+      const int b = rt.shift[k][threadIdx.x] + q, e = rt.shift[k][threadIdx.x] + rt.qend[k][threadIdx.x];
+      q = rt.qend[k][threadIdx.x];
       for (int j = b; j < e; j++) {
         const float4 pj = st.pos[j];
         if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.rec[j].vel : pj);
@@ -294,7 +305,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
-  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];  // used by the masked flavour only
+  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
   // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
@@ -311,7 +322,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<false>(P, st, start, nm, s, pi, cc, RunTable{rt_b, rt_len},
+    for_each_neighbour<false>(P, st, start, nm, s, pi, cc, RunTable{rt_shift, rt_qend},
                               [&](const float4& pj, const float4&) { add(dist2_to(pi, pj, dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
@@ -352,7 +363,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
-  __shared__ int rt_b[9][kBlock], rt_len[9][kBlock];  // used by the masked flavour only
+  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
   // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
   int base, bound;
   column_slots(P, start, P.own_lo, P.own_hi, base, bound);
@@ -381,7 +392,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, cc, RunTable{rt_b, rt_len}, add_pair);
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, cc, RunTable{rt_shift, rt_qend}, add_pair);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
