@@ -29,13 +29,14 @@ from sph_amd import capi, scenes  # noqa: E402
 from sph_amd.params import SPH_FLAG_SURFACE_TENSION  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+VALU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock
 
 # Algorithmic HBM bytes per particle and kernel: every array touched once per pass, neighbour
 # re-reads assumed served on-chip.
 BYTES_PER_PARTICLE = {
     "hash": 16,      # R pos 12, W cell 4
     "reorder": 56,   # R key 4 (histogram) ; R key 4 + R pos,vel 24 + W pos,vel 24 (scatter)
-    "search": 12,    # R pos 12 (+ neighbour bitmask W, 4 B per 32 candidates)
+    "search": 12,    # R pos 12 (+ candidate bitmask W, 4 B per 32 candidates)
     "density": 16,   # R pos 12, W rho 4
     "force": 52,     # R pos 12, vel 12, rho 4 ; W pos 12, vel 12
 }
@@ -96,14 +97,14 @@ def cpu_baseline(args):
     }
 
 
-def traffic_from_profile(workload_name):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary."""
+def from_profile(workload_name, key):
+    """A per-launch figure of the dominant kernel from the committed rocprofv3 --pmc summary of this workload."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if t.get("workload") == workload_name:
-            return t.get("force_bytes_per_launch")
+            return t.get(key)
     except (OSError, ValueError):
         pass
     return None
@@ -175,13 +176,22 @@ def main():
         achieved = BYTES_PER_PARTICLE["force"] * n / force_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(r["workload"]),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": from_profile(r["workload"], "force_bytes_per_launch"),
             "bytes_per_particle": BYTES_PER_PARTICLE["force"], "avg_launch_ms": per["force"],
         }
         df = (BYTES_PER_PARTICLE["density"] + BYTES_PER_PARTICLE["force"]) * n / (
             (per["search"] + per["density"] + per["force"]) * 1e-3) / 1e9
         out["roofline_density_force"] = {"bound": "hbm", "achieved": df, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": df / HBM_PEAK_GBS, "bytes_per_particle": 68}
+        # The sweeps are bound by vector-instruction issue, not by HBM: a wave64 instruction holds one of the
+        # chip's 1024 SIMDs for 4 cycles.  Instruction count per launch from the committed counter profile,
+        # duration live.
+        insts = from_profile(r["workload"], "force_valu_wave_insts_per_launch")
+        if insts:
+            peak = 1024 * VALU_CLOCK_HZ / 4.0
+            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_force", "achieved": insts / force_s, "peak": peak,
+                                    "unit": "wave-instructions/s", "frac": insts / force_s / peak,
+                                    "wave_insts_per_launch": insts}
         out["kernel_ms_per_step"] = per
     if not args.no_cpu_baseline and rank == 0:
         out["cpu_baseline"] = cpu_baseline(args)

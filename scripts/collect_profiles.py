@@ -36,6 +36,18 @@ def counters(kind):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v[-steps:]) / len(v[-steps:]) for k, v in agg.items()}
 
+def multi_counters(kind):
+    """{kernel: {counter: mean over the timed region}} of a pass that collected several counters."""
+    try:
+        f = newest(os.path.join(src, f"prof_{tag}_{kind}", "**", "*counter_collection.csv"))
+    except ValueError:
+        return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "sph::" in r["Kernel_Name"]:
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v[-steps:]) / len(v[-steps:]) for c, v in cs.items()} for k, cs in agg.items()}
+
 fetch, write = counters("fetch"), counters("write")
 n = bench["config"]["particles"]
 out = {"workload": bench["config"]["workload"], "particles": n, "steps_averaged": steps,
@@ -48,6 +60,26 @@ hash_read = 2 * fetch.get("k_hash", 0.0) * 1024.0
 out["calibration"] = {"k_hash_read_bytes_corrected": hash_read, "k_hash_read_bytes_expected": 12.0 * n}
 force = [k for k in out["kernels"] if k.startswith("k_force")]
 out["force_bytes_per_launch"] = out["kernels"][force[0]]["hbm_bytes_per_launch"] if force else None
+# issue side: SQ counters are summed over the device; a wave64 vector instruction occupies its SIMD for 4 cycles,
+# so 4 * SQ_INSTS_VALU / (SIMDs * kernel cycles) is the fraction of vector issue slots used
+sq, ta = multi_counters("sq"), multi_counters("ta")
+out["issue"] = {}
+for k, c in sq.items():
+    if "SQ_INSTS_VALU" not in c:
+        continue
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
+    row = {"valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
+           "valu_issue_frac": 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc) if cyc else None,
+           "lane_utilisation": c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_INSTS_VALU"]),
+           "waves_per_simd": 4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (1024.0 * cyc) if cyc else None,
+           "wave_time_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None}
+    t = ta.get(k, {})
+    if t.get("GRBM_GUI_ACTIVE"):
+        row["ta_busy_frac"] = t.get("TA_BUSY_avr", 0.0) / (t["GRBM_GUI_ACTIVE"] / 8.0)
+        if t.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            row["l1_hit_frac"] = 1.0 - t.get("TCP_TCC_READ_REQ_sum", 0.0) / t["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    out["issue"][k] = row
+out["force_valu_wave_insts_per_launch"] = out["issue"].get(force[0], {}).get("valu_wave_insts_per_launch") if force else None
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(stats)))
@@ -57,3 +89,5 @@ for r in rows[:10]:
 print("  calibration k_hash read: %.1f MB corrected vs %.1f MB expected" % (hash_read / 1e6, 12.0 * n / 1e6))
 for k, v in out["kernels"].items():
     print("  %-22s hbm %8.1f MB/launch" % (k, v["hbm_bytes_per_launch"] / 1e6))
+for k, v in out["issue"].items():
+    print("  %-22s" % k, " ".join("%s=%.3g" % (a, b) for a, b in v.items() if b is not None))

@@ -184,38 +184,50 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
 }
 
 // Lanes of a wave run in lockstep, so a wave takes as long as its particle with the most neighbours.  Hand the
-// block's 256 particles (slots lo + 256*blk ...) to lanes in order of decreasing neighbour count (8-wide bins,
-// counting sort in LDS).  Which lane advances which particle has no influence on any result.
-// Returns the index within the block that this lane takes.
+// block's particles to lanes in order of decreasing neighbour count (counting sort in LDS, one bin per count),
+// so that every wave gets particles of nearly equal load.  Which lane advances which particle has no influence on
+// any result.  Returns the index within the block that this lane takes.
+constexpr int kLoadBins = 256;  // counts of kLoadBins - 1 and more share a bin
 __device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count, -1 for a lane without a particle
-  __shared__ int bin_fill[66];
+  __shared__ int bin_fill[kLoadBins + 1];
+  __shared__ int wave_total[kBlock / 64];
   __shared__ unsigned short perm[kBlock];
-  const int bin = k < 0 ? 64 : 63 - (k >> 3 > 63 ? 63 : k >> 3);  // idle lanes last
-  for (int i = threadIdx.x; i < 66; i += blockDim.x) bin_fill[i] = 0;
+  static_assert(kLoadBins % kBlock == 0 || kBlock % kLoadBins == 0, "bins are scanned kBlock at a time");
+  const int bin = k < 0 ? kLoadBins : kLoadBins - 1 - (k < kLoadBins - 1 ? k : kLoadBins - 1);  // idle lanes last
+  for (int i = threadIdx.x; i <= kLoadBins; i += kBlock) bin_fill[i] = 0;
   __syncthreads();
   const int rank = atomicAdd(&bin_fill[bin], 1);
   __syncthreads();
-  if (threadIdx.x < 64) {  // first wave: exclusive prefix sum over bins 0..63, bin 64 (idle lanes) after them
-    const int c = bin_fill[threadIdx.x];
+  // exclusive prefix sum over the bins, kBlock bins per round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < kLoadBins; base += kBlock) {
+    const int i = base + threadIdx.x;
+    const int c = i < kLoadBins ? bin_fill[i] : 0;
     int incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if ((int)threadIdx.x >= d) incl += up;
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
     }
-    bin_fill[threadIdx.x] = incl - c;
-    if (threadIdx.x == 63) bin_fill[64] = incl;
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int before = carry, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+      if (w < wave) before += wave_total[w];
+      all += wave_total[w];
+    }
+    if (i < kLoadBins) bin_fill[i] = before + incl - c;
+    carry += all;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) bin_fill[kLoadBins] = carry;
   __syncthreads();
   perm[bin_fill[bin] + rank] = (unsigned short)threadIdx.x;
   __syncthreads();
   return perm[threadIdx.x];
 }
-__device__ inline int lane_by_load(const NeighbourMask& nm, int first_slot, int hi) {
-  const int s_nat = first_slot + threadIdx.x;
-  return lane_by_count(s_nat < hi ? nm.nnb[s_nat] : -1);
-}
-
 // Walks the set bits of particle slot s's candidate mask in order and calls visit(pos_j, vel_j) for each; load(j,
 // pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
 // of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
@@ -271,12 +283,11 @@ __device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, cons
 // bits (cells crowded beyond ~75 particles each) or the search left no mask.
 template <bool WITH_VEL, class Visit>
 __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
-                                          const NeighbourMask& nm, int s, const float4& pi, const CellCoord cc,
-                                          const RunTable& rt, Visit visit) {
+                                          const NeighbourMask& nm, int s, const float4& pi, const RunTable& rt,
+                                          int col, Visit visit) {
   const int ncand = nm.ncand[s];
-  fill_runs(P, start, cc, rt);
   if (ncand <= kMaskBits) {
-    walk_mask(nm, s, ncand, rt, threadIdx.x,
+    walk_mask(nm, s, ncand, rt, col,
               [&](int j, float4& pj, float4& vj) {
                 if (WITH_VEL) {
                   pj = st.rec[j].pos;
@@ -289,8 +300,8 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
   } else {
     float dx, dy, dz;
     for (int k = 0, q = 0; k < 9; k++) {
-      const int b = rt.shift[k][threadIdx.x] + q, e = rt.shift[k][threadIdx.x] + rt.qend[k][threadIdx.x];
-      q = rt.qend[k][threadIdx.x];
+      const int b = rt.shift[k][col] + q, e = rt.shift[k][col] + rt.qend[k][col];
+      q = rt.qend[k][col];
       for (int j = b; j < e; j++) {
         const float4 pj = st.pos[j];
         if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.rec[j].vel : pj);
@@ -310,7 +321,15 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
   const int first = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x;
-  const int s = first + (MODE == SWEEP_MASKED ? lane_by_load(nm, first, hi) : (int)threadIdx.x);
+  int col = threadIdx.x;
+  if (MODE == SWEEP_MASKED) {
+    // stencil runs of the block's particles, fetched by the lanes in slot order while the loads are binned
+    const int s_nat = first + threadIdx.x;
+    const int load = s_nat < hi ? nm.nnb[s_nat] : -1;
+    if (s_nat < hi) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTable{rt_shift, rt_qend});
+    col = lane_by_count(load);  // its barriers publish the run table
+  }
+  const int s = first + col;
   if (s >= hi) return;
   const float4 pi = st.pos[s];
   const CellCoord cc = decode_cell(P, cell_s[s]);
@@ -322,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<false>(P, st, start, nm, s, pi, cc, RunTable{rt_shift, rt_qend},
+    for_each_neighbour<false>(P, st, start, nm, s, pi, RunTable{rt_shift, rt_qend}, col,
                               [&](const float4& pj, const float4&) { add(dist2_to(pi, pj, dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
@@ -373,7 +392,14 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     n_own_out[1] = start[real + 1] - start[real];  // trash cell: particles outside the local grid
   }
   const int first = xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x;
-  const int o = first + (MODE == SWEEP_MASKED ? lane_by_load(nm, base + first, bound) : (int)threadIdx.x);
+  int col = threadIdx.x;
+  if (MODE == SWEEP_MASKED) {
+    const int s_nat = base + first + threadIdx.x;
+    const int load = s_nat < bound ? nm.nnb[s_nat] : -1;
+    if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTable{rt_shift, rt_qend});
+    col = lane_by_count(load);
+  }
+  const int o = first + col;
   const int s = base + o;
   if (s >= bound) return;
   const float4 pi4 = st.pos[s];
@@ -392,7 +418,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, cc, RunTable{rt_shift, rt_qend}, add_pair);
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTable{rt_shift, rt_qend}, col, add_pair);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
