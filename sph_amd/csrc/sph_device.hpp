@@ -18,6 +18,23 @@ __device__ inline int cell_coord(float x, float cell, int gn) {
 
 __device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
 
+// Correctly rounded fp32 square root (what sqrtf gives on the reference's host), for the r of :143.
+// hipcc expands sqrtf into v_sqrt_f32 (1 ulp) plus a correction: the candidates one ulp below and above are
+// tried with exact fma residuals.  Around that it scales arguments below 2^-96 (v_sqrt_f32 does not take
+// denormals) and patches 0 and inf.  Here every argument is a squared distance: 0 for the particle itself,
+// which the correction below leaves at 0 (both residual tests fail), or far above 2^-96 for any two fp32
+// positions that differ - the scaling is kept for the arguments that need it, behind a branch no wave takes.
+__device__ inline float sqrt_rn(float x) {
+  if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return sqrtf(x);
+  float s = __builtin_amdgcn_sqrtf(x);
+  const int bits = __float_as_int(s);
+  const float below = __int_as_float(bits - 1), above = __int_as_float(bits + 1);
+  const float e_below = __builtin_fmaf(-below, s, x), e_above = __builtin_fmaf(-above, s, x);
+  s = e_below <= 0.0f ? below : s;
+  s = e_above > 0.0f ? above : s;
+  return s;
+}
+
 // ---- smoothing kernels, compute.cpp:41-95 (callers guarantee r <= h) -------------------------------
 __device__ inline float w_poly6(const DevParams& P, float r) {  // :61-71
   float rr = r * r;
@@ -77,7 +94,7 @@ __device__ inline float div_by(float a, float b, float y) {  // y = refined_rcp(
 __device__ inline PairOut pair_eval(const DevParams& P, float dx, float dy, float dz, float r2, float pi,
                                     float rho_j, float dvx, float dvy, float dvz) {
   PairOut o;
-  float r = sqrtf(r2);
+  float r = sqrt_rn(r2);
   float ux = 0.0f, uy = 0.0f, uz = 0.0f;  // vecNormalize(r, r)  :28-39
   if (r > 0.0f) {
     const float yr = refined_rcp(r);

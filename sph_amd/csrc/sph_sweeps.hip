@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   int cnt = 0;
   float dx, dy, dz;
   auto add = [&](float r2) {
-    acc += P.m * w_poly6(P, sqrtf(r2));  // :144-146
+    acc += P.m * w_poly6(P, sqrt_rn(r2));  // :144-146
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
