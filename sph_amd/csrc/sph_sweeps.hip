@@ -28,10 +28,7 @@ namespace sph {
 
 namespace {
 
-#ifndef SPH_KBLOCK
-#define SPH_KBLOCK 256
-#endif
-constexpr int kBlock = SPH_KBLOCK;
+constexpr int kBlock = 256;
 constexpr int kAhead = 4;  // candidates fetched per loop trip of the search: independent loads in flight per lane
 constexpr int kMaskBits = 32 * kMaskWords;
 
