@@ -97,6 +97,24 @@ def cpu_baseline(args):
     }
 
 
+def cpu_grid_twin(args):
+    """This repository's uniform-grid CPU twin (NOT the reference algorithm: same arithmetic and results, but
+    O(N) neighbour search) on the full workload, for a CPU figure at the size the GPU number is quoted on."""
+    from oracle import Oracle  # checker only: timed here as a reported CPU figure
+    pos, vel, p = scenes.dam_break(args.side)
+    orc = Oracle()
+    orc.step_grid(p, pos, vel, order=0)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 5.0 and reps < 20):
+        orc.step_grid(p, pos, vel, order=0)
+        reps += 1
+    per_step = (time.perf_counter() - t0) / reps
+    return {"value": pos.shape[0] / per_step, "unit": "particle-updates/s", "cores": orc.num_threads(),
+            "kind": "port, uniform-grid search (not the reference's all-pairs algorithm)",
+            "sample": f"{reps} steps of the full {pos.shape[0]}-particle dam break ({per_step:.3f} s/step)"}
+
+
 def from_profile(workload_name, key):
     """A per-launch figure of the dominant kernel from the committed rocprofv3 --pmc summary of this workload."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -195,6 +213,8 @@ def main():
         out["kernel_ms_per_step"] = per
     if not args.no_cpu_baseline and rank == 0:
         out["cpu_baseline"] = cpu_baseline(args)
+        if args.workload == "dam_break":
+            out["cpu_grid_twin"] = cpu_grid_twin(args)
     print(json.dumps(out))
 
 
