@@ -41,6 +41,9 @@ struct ParticleRec {
   float4 pos;  // x, y, z, unused
   float4 vel;  // vx, vy, vz, density (w is written by the density pass)
 };
+// The neighbour search reads up to kSearchOverread slots past the end of a stencil run (and masks them off), so
+// `pos` is allocated that much longer than the particle capacity.
+constexpr int kSearchOverread = 4;
 struct Sorted {
   float4* pos;
   ParticleRec* rec;

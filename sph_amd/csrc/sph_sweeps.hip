@@ -156,16 +156,19 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
       continue;
     }
     const int m = qe - q < kAhead ? qe - q : kAhead;
-    const int j = shift + q;
+    // Always fetch kAhead consecutive slots from one base address: past the end of the run they belong to the
+    // next cell or to the array's padding, and their outcomes are masked off below.
+    const float4* base = st.pos + (shift + q);
     float4 cand[kAhead];
 #pragma unroll
-    for (int u = 0; u < kAhead; u++) cand[u] = st.pos[u < m ? j + u : j];
+    for (int u = 0; u < kAhead; u++) cand[u] = base[u];
     unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < kAhead; u++) {
       const float r2 = dist2_to(pi, cand[u], dx, dy, dz);
-      bits |= (u < m && r2 <= P.r2_max ? 1u : 0u) << u;
+      bits |= (r2 <= P.r2_max ? 1u : 0u) << u;
     }
+    bits &= (1u << m) - 1u;
     cnt += __popc(bits);
     const int sh = q & 31;
     word |= bits << sh;
