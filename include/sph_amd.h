@@ -229,8 +229,16 @@ int sph_slab_append(sph_context* ctx, const float* d_rec, int n_rec);
 
 /* Particles per OWN column at the last sort (host array, ncols = col_hi - col_lo entries). */
 int sph_slab_column_counts(sph_context* ctx, int32_t* counts, int capacity, int* ncols);
-/* Total number of particles dropped so far because they left the local grid (should be 0). */
+/* Total number of RECEIVED records so far whose x-column lay outside this context's local grid (own
+ * columns +- 2): particles that no context integrates any more.  Must stay 0; it cannot stay 0 when
+ * particles cross more columns per step than the neighbouring slab is wide (see
+ * sph_slab_max_column_shift).  Own particles that leave the local grid are not counted: sph_slab_pack
+ * handed them to the neighbour first. */
 int sph_slab_lost(sph_context* ctx, int64_t* lost);
+/* max |vx| * timestep / cell edge over the context's particles: the number of columns a particle can
+ * cross in the next step.  With one exchange per step between direct neighbours, every slab must be
+ * at least ceil(that) + 2 columns wide (+ 1 while cut planes move).  Synchronous. */
+int sph_slab_max_column_shift(sph_context* ctx, float* columns);
 
 /* The HIP stream (hipStream_t) all of the context's work is issued on; sph_set_stream makes the
  * context issue on a caller-owned stream instead (e.g. the stream a communication library

@@ -52,6 +52,7 @@ _SIGNATURES = [
     ("sph_slab_append", C.c_int, [_CTX, C.c_void_p, C.c_int]),
     ("sph_slab_column_counts", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("sph_slab_lost", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
+    ("sph_slab_max_column_shift", C.c_int, [_CTX, C.POINTER(C.c_float)]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
 ]
@@ -289,6 +290,12 @@ class SlabSimulation:
         v = C.c_int64()
         _check(self.lib.sph_slab_lost(self._ctx, C.byref(v)))
         return v.value
+
+    def max_column_shift(self):
+        """Columns a particle can cross in the next step: max |vx| * dt / cell over this slab's particles."""
+        v = C.c_float()
+        _check(self.lib.sph_slab_max_column_shift(self._ctx, C.byref(v)))
+        return float(v.value)
 
     # -- the per-step protocol -----------------------------------------------------------------------
     def pack(self):

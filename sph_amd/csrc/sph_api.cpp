@@ -62,6 +62,7 @@ struct sph_context {
   int n_last_own = 0;                 // particles integrated by the last step (debug downloads)
   int dbg_stride = 0;                 // plane stride of dbg.force = particle count the last step was launched with
   int32_t* d_counters = nullptr;      // [0],[1] pack counters  [2] own count  [3] trash count after a step
+                                      // [4] stray received records (cumulative)  [5] max column shift (float bits)
   int32_t* h_counters = nullptr;      // pinned mirror
   int32_t* d_colcounts = nullptr;     // [cols_capacity + 4]
   bool n_pending = false;             // true count of `cur` still travelling to h_counters[2]
@@ -247,7 +248,7 @@ int resolve_n(sph_context* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->n = c->h_counters[2];
   c->n_last_own = c->n;
-  c->lost += c->h_counters[3];
+  c->lost = c->h_counters[4];  // cumulative on the device
   c->n_pending = false;
   return SPH_OK;
 }
@@ -276,7 +277,7 @@ int one_step(sph_context* c) {
   c->dbg_stride = n;
   if (c->slab) {
     // ghosts and emigrants drop out here: only own-column particles were written back
-    HIP_TRY(hipMemcpyAsync(c->h_counters + 2, c->d_counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(c->h_counters + 2, c->d_counters + 2, 3 * sizeof(int32_t), hipMemcpyDeviceToHost,
                            c->stream));
     c->n_pending = true;
   } else {
@@ -714,7 +715,7 @@ int sph_slab_append(sph_context* c, const float* d_rec, int n_rec) {
     return fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", c->n, n_rec, c->n_max);
   {
     Timed t(c, CAT_OTHER);
-    launch_slab_append(c->stream, d_rec, n_rec, c->cur, c->n);
+    launch_slab_append(c->stream, c->dev, d_rec, n_rec, c->cur, c->n, c->d_counters + 4);
   }
   HIP_TRY(hipGetLastError());
   c->n += n_rec;
@@ -742,7 +743,25 @@ int sph_slab_lost(sph_context* c, int64_t* lost) {
   HIP_TRY(hipSetDevice(c->device));
   int rc = resolve_n(c);
   if (rc) return rc;
+  // records appended since the last step have not been through resolve_n yet
+  HIP_TRY(hipMemcpyAsync(c->h_counters + 4, c->d_counters + 4, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->lost = c->h_counters[4];
   *lost = c->lost;
+  return SPH_OK;
+}
+
+int sph_slab_max_column_shift(sph_context* c, float* columns) {
+  if (!c || !columns) return fail(SPH_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(c->d_counters + 5, 0, sizeof(int32_t), c->stream));
+  launch_max_column_shift(c->stream, c->dev, c->cur, c->n, c->d_counters + 5);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_counters + 5, c->d_counters + 5, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(columns, c->h_counters + 5, sizeof(float));
   return SPH_OK;
 }
 

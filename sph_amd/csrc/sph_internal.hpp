@@ -99,7 +99,9 @@ void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const Sta
                   SweepMode mode);
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
                       bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters);
-void launch_slab_append(hipStream_t s, const float* rec, int n_rec, const State& st, int at);
+void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int n_rec, const State& st, int at,
+                        int32_t* stray);
+void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out);
 void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, const int32_t* ids, int n, State st);
 void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);

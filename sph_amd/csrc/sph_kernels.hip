@@ -270,7 +270,11 @@ __global__ void k_slab_pack(DevParams P, State st, int n, int col_lo, int col_hi
   }
 }
 
-__global__ void k_slab_append(const float* __restrict__ rec, int n_rec, State st, int at) {
+// Received records join the particle set.  A record whose x-column lies outside this context's local grid
+// (own columns +- 2) can be neither integrated nor used as a ghost here and nobody else holds it: it is counted
+// in *stray (the slabs are too narrow for the distance particles travel per step).
+__global__ void k_slab_append(DevParams P, const float* __restrict__ rec, int n_rec, State st, int at,
+                              int32_t* __restrict__ stray) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_rec) return;
   const float* r = rec + (size_t)k * kRecWords;
@@ -282,6 +286,19 @@ __global__ void k_slab_append(const float* __restrict__ rec, int n_rec, State st
   st.vy[i] = r[4];
   st.vz[i] = r[5];
   st.id[i] = __float_as_int(r[6]);
+  const int cx = cell_coord(r[0], P.cell, P.gnx) - P.cx_off;
+  if (cx < 0 || cx >= P.nx) atomicAdd(stray, 1);
+}
+
+// Largest |vx| * dt / cell over the particles: how many cell columns a particle can cross in the next step.
+// Non-negative floats order like their bit patterns, so the maximum is taken with an integer atomic.
+__global__ void __launch_bounds__(kBlock) k_max_column_shift(DevParams P, State st, int n, int32_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = i < n ? fabsf(st.vx[i]) * P.dt / P.cell : 0.0f;
+  if (!(v >= 0.0f)) v = 0.0f;  // NaN
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(out, __float_as_int(v));
 }
 
 __global__ void k_split_aos_ids(const float* __restrict__ pos, const float* __restrict__ vel,
@@ -376,9 +393,15 @@ void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n,
                      has_left ? 1 : 0, has_right ? 1 : 0, rec_left, rec_right, cap, counters);
 }
 
-void launch_slab_append(hipStream_t s, const float* rec, int n_rec, const State& st, int at) {
+void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_max_column_shift, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, out);
+}
+
+void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int n_rec, const State& st, int at,
+                        int32_t* stray) {
   if (n_rec <= 0) return;
-  hipLaunchKernelGGL(k_slab_append, dim3(div_up(n_rec, kBlock)), dim3(kBlock), 0, s, rec, n_rec, st, at);
+  hipLaunchKernelGGL(k_slab_append, dim3(div_up(n_rec, kBlock)), dim3(kBlock), 0, s, P, rec, n_rec, st, at, stray);
 }
 
 void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, const int32_t* ids, int n, State st) {

@@ -50,9 +50,21 @@ def partition_columns(hist, nranks, min_cols=MIN_SLAB_COLUMNS):
     return cuts
 
 
+def min_columns_for_shift(max_shift_columns):
+    """Narrowest slab that one exchange per step between direct neighbours can serve.
+
+    A particle that crosses D columns in a step must still land in its old owner's own or neighbouring
+    slab (+- 2 ghost columns): every slab has to be ceil(D) + 2 columns wide, + 1 while the cut planes
+    themselves move by a column.
+    """
+    return max(MIN_SLAB_COLUMNS, int(np.ceil(max_shift_columns)) + 3)
+
+
 def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
     """Move every interior cut by at most max_shift columns towards the balanced partition."""
     nranks = len(cuts) - 1
+    ncols = cuts[-1]
+    min_cols = min(min_cols, ncols // nranks)  # never ask for more than the tank can give
     ideal = partition_columns(hist, nranks, min_cols)
     new = list(cuts)
     for r in range(1, nranks):
@@ -63,6 +75,10 @@ def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
         new[r] = max(new[r], new[r - 1] + min_cols)
     for r in range(nranks - 1, 0, -1):
         new[r] = min(new[r], new[r + 1] - min_cols)
+    # ... but never by more than max_shift per call: the exchange of one step covers a face that moved one
+    # column, not more (a slab that is still too narrow keeps widening on the following calls)
+    for r in range(1, nranks):
+        new[r] = int(np.clip(new[r], cuts[r] - max_shift, cuts[r] + max_shift))
     return new
 
 
@@ -152,6 +168,12 @@ class DistExchange:
     def _in(self, t):
         return t if t.device == self.data_device else t.to(self.data_device)
 
+    def allreduce_max(self, value):
+        torch, dist = self.torch, self.dist
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def allgather_histogram(self, local_hist, cuts, ncols):
         """Global per-column particle histogram from every rank's own-column counts."""
         torch, dist = self.torch, self.dist
@@ -173,6 +195,7 @@ class SlabRunner:
         self.cuts = list(cuts)
         self.rebalance_every = rebalance_every
         self.steps_done = 0
+        self.min_cols = MIN_SLAB_COLUMNS
 
     def step(self):
         b = self.backend
@@ -188,7 +211,9 @@ class SlabRunner:
     def rebalance(self):
         b = self.backend
         hist = self.exchange.allgather_histogram(b.column_counts(), self.cuts, self.cuts[-1])
-        new = rebalance_cuts(self.cuts, hist)
+        shift = self.exchange.allreduce_max(b.max_column_shift()) if hasattr(b, "max_column_shift") else 0.0
+        self.min_cols = min_columns_for_shift(shift)
+        new = rebalance_cuts(self.cuts, hist, min_cols=self.min_cols)
         if new != self.cuts:
             self.cuts = new
             b.set_columns(new[self.rank], new[self.rank + 1])
@@ -213,7 +238,8 @@ def rebalance_local_slabs(backends, cuts):
     for r, b in enumerate(backends):
         c = b.column_counts()
         hist[cuts[r]:cuts[r] + len(c)] = c
-    new = rebalance_cuts(cuts, hist)
+    shift = max((b.max_column_shift() for b in backends if hasattr(b, "max_column_shift")), default=0.0)
+    new = rebalance_cuts(cuts, hist, min_cols=min_columns_for_shift(shift))
     if new != list(cuts):
         for r, b in enumerate(backends):
             b.set_columns(new[r], new[r + 1])

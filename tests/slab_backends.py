@@ -19,6 +19,7 @@ class OracleSlabBackend:
         self.ids = np.zeros(0, np.int32)
         self.last_counts = None
         self.debug = None
+        self.stray = 0
 
     def _cols(self, pos):
         if pos.shape[0] == 0:
@@ -56,6 +57,8 @@ class OracleSlabBackend:
         if rec is None or rec.shape[0] == 0:
             return
         r = rec.cpu().numpy()
+        c = self._cols(np.ascontiguousarray(r[:, 0:3]))
+        self.stray += int(((c < self.lo - 2) | (c >= self.hi + 2)).sum())
         self.pos = np.concatenate([self.pos, r[:, 0:3]])
         self.vel = np.concatenate([self.vel, r[:, 3:6]])
         self.ids = np.concatenate([self.ids, np.ascontiguousarray(r[:, 6]).view(np.int32)])
@@ -71,6 +74,15 @@ class OracleSlabBackend:
 
     def column_counts(self):
         return self.last_counts
+
+    def lost(self):
+        return self.stray
+
+    def max_column_shift(self):
+        if self.vel.shape[0] == 0:
+            return 0.0
+        cell = np.float32(self.params.h) * np.float32(1.000244140625)
+        return float(np.abs(self.vel[:, 0]).max() * np.float32(self.params.timestep) / cell)
 
     def download(self):
         return self.pos, self.vel, self.ids

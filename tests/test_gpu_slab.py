@@ -9,7 +9,7 @@ from conftest import bits_equal
 
 from sph_amd import capi, scenes, slab
 from sph_amd.params import SPH_FLAG_KEEP_DEBUG, SPH_FLAG_SURFACE_TENSION, default_params
-from test_slab_cpu import by_id, moving_block
+from test_slab_cpu import by_id, fast_jet, moving_block
 
 pytestmark = pytest.mark.gpu
 DBG = SPH_FLAG_SURFACE_TENSION | SPH_FLAG_KEEP_DEBUG
@@ -105,6 +105,54 @@ def test_dam_break_slabs_at_scale(oracle):
     assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
     loads = [b.n for b in backends]
     assert max(loads) < 1.6 * ids.size / 4, f"rebalancing left the slabs unbalanced: {loads}"
+    for b in backends:
+        b.close()
+
+
+def test_particles_crossing_several_columns_per_step(oracle):
+    """A jet at 2.5 columns per step over 3 slabs as wide as min_columns_for_shift asks for: nothing strays,
+    and the result is the single context's bit for bit; the same jet over 4-column slabs is reported."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = fast_jet()
+    gn = capi.global_cells(p)
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    shift = float(np.abs(vel[:, 0]).max() * 0.005 / 0.01)
+    cuts = slab.partition_columns(np.ones(gn, np.int64), 3, slab.min_columns_for_shift(shift))
+    backends = []
+    for r in range(3):
+        b = capi.SlabSimulation(p, n_max=ids.size, col_lo=cuts[r], col_hi=cuts[r + 1], cols_capacity=gn)
+        m = (cols >= cuts[r]) & (cols < cuts[r + 1])
+        b.upload(pos[m], vel[m], ids[m])
+        backends.append(b)
+    assert abs(max(b.max_column_shift() for b in backends if b.n) - shift) < 0.01 * shift
+    ex = slab.LocalExchange(3)
+    with capi.Simulation(p, n_max=ids.size) as single:
+        single.upload(pos, vel)
+        for s in range(5):
+            step_and_sync(backends, ex)
+            cuts = slab.rebalance_local_slabs(backends, cuts)
+        single.step(5)
+        rp, rv = single.download()
+    assert all(b.lost() == 0 for b in backends)
+    got = by_id(*[np.concatenate(x) for x in zip(*[b.download() for b in backends])])
+    assert np.array_equal(got[2], ids)
+    assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
+    for b in backends:
+        b.close()
+
+    pos, vel, ids = fast_jet(speed=16.0)
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    cuts = [0, 4, 8, 12, gn]
+    backends = []
+    for r in range(4):
+        b = capi.SlabSimulation(p, n_max=ids.size, col_lo=cuts[r], col_hi=cuts[r + 1], cols_capacity=gn)
+        m = (cols >= cuts[r]) & (cols < cuts[r + 1])
+        b.upload(pos[m], vel[m], ids[m])
+        backends.append(b)
+    ex = slab.LocalExchange(4)
+    for s in range(3):
+        step_and_sync(backends, ex)
+    assert sum(b.lost() for b in backends) > 0
     for b in backends:
         b.close()
 

@@ -61,6 +61,76 @@ def test_rebalance_moves_one_column_at_a_time():
     assert cuts[1] == 10  # converged to the balanced cut
 
 
+def test_min_width_follows_the_column_shift_and_cuts_move_one_column():
+    assert slab.min_columns_for_shift(0.0) == slab.MIN_SLAB_COLUMNS
+    assert slab.min_columns_for_shift(0.4) == 4
+    assert slab.min_columns_for_shift(2.2) == 6
+    hist = np.full(40, 100, np.int64)
+    cuts = [0, 4, 8, 40]  # far from balanced (13/13/14) and narrower than 7 columns
+    new = slab.rebalance_cuts(cuts, hist, min_cols=7)
+    assert all(abs(a - b) <= 1 for a, b in zip(new, cuts)), "a face moves one column per call at most"
+    for _ in range(40):
+        new = slab.rebalance_cuts(new, hist, min_cols=7)
+    assert min(np.diff(new)) >= 7 and new == slab.partition_columns(hist, 3, 7)
+
+
+def fast_jet(n_side=10, speed=5.0, seed=5):
+    """Block moving in +x at ~speed m/s: 5 m/s * 0.005 s = 2.5 cell columns per step."""
+    pos, vel, ids = scenes.jittered_lattice(n_side, n_side, n_side, origin=(0.02, 0.05, 0.05), seed=seed,
+                                            return_ids=True)
+    rng = np.random.default_rng(seed)
+    vel = (rng.random(vel.shape, dtype=np.float32) * np.float32(0.2)).astype(np.float32)
+    vel[:, 0] += np.float32(speed)
+    return pos, vel, ids
+
+
+def test_particles_crossing_several_columns_per_step(oracle):
+    """A jet that crosses 2.5 columns per step: slabs as wide as min_columns_for_shift asks for hand every
+    particle to the right owner with the one-hop exchange (nothing strays), bit-identical to one domain."""
+    p = default_params()
+    pos, vel, ids = fast_jet()
+    gn = oracle.consts(p).ncell
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    shift = float(np.abs(vel[:, 0]).max() * 0.005 / 0.01)
+    cuts = slab.partition_columns(np.ones(gn, np.int64), 3, slab.min_columns_for_shift(shift))
+    backends = []
+    for r in range(3):
+        b = OracleSlabBackend(oracle, p, cuts[r], cuts[r + 1])
+        m = (cols >= cuts[r]) & (cols < cuts[r + 1])
+        b.upload(pos[m], vel[m], ids[m])
+        backends.append(b)
+    ex = slab.LocalExchange(3)
+    rp, rv = pos.copy(), vel.copy()
+    for s in range(5):
+        slab.step_local_slabs(backends, ex)
+        cuts = slab.rebalance_local_slabs(backends, cuts)
+        oracle.step_grid(p, rp, rv, ids, order=0)
+        assert sum(b.n for b in backends) == ids.size
+    assert all(b.lost() == 0 for b in backends)
+    got = by_id(*[np.concatenate(x) for x in zip(*[b.download() for b in backends])])
+    assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
+    assert backends[1].n + backends[2].n > 0, "the jet must have crossed a cut plane"
+
+
+def test_too_narrow_slabs_report_stray_particles(oracle):
+    """The same jet over 4-column slabs: particles jump over a whole slab; the receiver counts them."""
+    p = default_params()
+    pos, vel, ids = fast_jet(speed=16.0)
+    gn = oracle.consts(p).ncell
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    cuts = [0, 4, 8, 12, gn]
+    backends = []
+    for r in range(4):
+        b = OracleSlabBackend(oracle, p, cuts[r], cuts[r + 1])
+        m = (cols >= cuts[r]) & (cols < cuts[r + 1])
+        b.upload(pos[m], vel[m], ids[m])
+        backends.append(b)
+    ex = slab.LocalExchange(4)
+    for s in range(3):
+        slab.step_local_slabs(backends, ex)
+    assert sum(b.lost() for b in backends) > 0
+
+
 # ---- several slabs in one process -------------------------------------------------------------------------
 
 @pytest.mark.parametrize("nslabs,rebalance", [(2, False), (3, False), (3, True)])
