@@ -356,6 +356,37 @@ def test_1m_matches_grid_twin_bitwise(oracle, dam_1m):
     assert bits_equal(gp, po) and bits_equal(gv, vo)
 
 
+def test_1m_compressed_phase_matches_grid_twin_bitwise(oracle, dam_1m):
+    """70 steps into the collapse the fluid is compressed to ~50 neighbours and ~300 candidates per particle
+    (longer masks, fuller cells, heavier load binning): take that state and compare one more step."""
+    pos, vel, p = dam_1m
+    q = p.copy(); q.flags = DBG
+    with capi.Simulation(q, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        sim.step(70)
+        mp, mv = sim.download()
+        po, vo = mp.copy(), mv.copy()
+        sim.upload(mp, mv)
+        rho_o, f_o, nc_o = oracle.step_grid(q, po, vo, order=0, want_debug=True)
+        sim.step(1)
+        rho, f, nc, _ = sim.download_debug()
+        gp, gv = sim.download()
+    assert nc_o.mean() > 40 and nc_o.max() > 100
+    assert np.array_equal(nc, nc_o)
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po) and bits_equal(gv, vo)
+
+
+def test_16m_uniform_cube_matches_grid_twin_bitwise(oracle):
+    """The largest single-GPU configuration (256^3 jittered lattice filling its tank): one step against the
+    CPU grid twin, every particle, every bit."""
+    pos, vel, p = scenes.uniform_cube(256)
+    q = p.copy(); q.flags = SPH_FLAG_SURFACE_TENSION
+    po, vo = pos.copy(), vel.copy()
+    oracle.step_grid(q, po, vo, order=0)
+    (gp, gv), _ = run_gpu(q, pos, vel, 1)
+    assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
 def test_1m_long_run_stays_in_tank(dam_1m):
     pos, vel, p = dam_1m
     (gp, gv), _ = run_gpu(p, pos, vel, 100)
