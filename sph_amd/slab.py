@@ -105,9 +105,16 @@ class DistExchange:
 
     With the "nccl" backend (RCCL on ROCm) the record tensors stay in HBM and travel over xGMI;
     with "gloo" they are staged through host memory (CPU tests, single-GPU rehearsals).
+
+    A message's size must be known to both ends before it is posted.  The first step therefore takes
+    two rounds (counts, then payload of exactly that size).  From then on one round per step: both ends
+    size the next message from the count of the last one plus `headroom` - the sender knows what it sent,
+    the receiver what it got, so they agree without talking - and the message carries its true record
+    count in a header record.  The rare message that outgrows its agreed size sends the remainder in a
+    second round, whose size both ends derive from that header.
     """
 
-    def __init__(self, rank, nranks, device=None, group=None):
+    def __init__(self, rank, nranks, device=None, group=None, headroom=1.25, min_capacity=1024):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -116,13 +123,82 @@ class DistExchange:
         self.device = device if self.on_device else torch.device("cpu")
         self.data_device = device if device is not None else torch.device("cpu")
         self.bytes_sent = 0
+        self.rounds = 0
+        self.headroom, self.min_capacity = float(headroom), int(min_capacity)
+        self.cap_out = {}   # neighbour rank -> records the next message to it holds
+        self.cap_in = {}    # neighbour rank -> records the next message from it holds
+        self.buf_out, self.buf_in = {}, {}
 
     def _neighbours(self):
         left = self.rank - 1 if self.rank > 0 else None
         right = self.rank + 1 if self.rank < self.nranks - 1 else None
         return left, right
 
+    def _capacity_after(self, count):
+        want = int(count * self.headroom) + 1
+        return max(self.min_capacity, (want + 255) // 256 * 256)
+
+    def _buffer(self, table, peer, rows):
+        t = table.get(peer)
+        if t is None or t.shape[0] < rows:
+            t = self.torch.empty((rows, RECORD_WORDS), dtype=self.torch.float32, device=self.device)
+            table[peer] = t
+        return t
+
+    def _batch(self, ops):
+        if ops:
+            self.rounds += 1
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
     def exchange(self, send_left, send_right):
+        left, right = self._neighbours()
+        peers = [(left, send_left), (right, send_right)]
+        if any(p is not None and p not in self.cap_out for p, _ in peers):
+            return self._exchange_two_rounds(send_left, send_right)
+        torch, dist = self.torch, self.dist
+        ops, sent = [], {}
+        for peer, send in peers:
+            if peer is None:
+                continue
+            k, cap = int(send.shape[0]), self.cap_out[peer]
+            msg = self._buffer(self.buf_out, peer, cap + 1)
+            msg[0].fill_(float(k))  # header record: the true count (exact in fp32 far beyond any halo)
+            m = min(k, cap)
+            if m:
+                msg[1:1 + m].copy_(send[:m] if self.on_device else send[:m].detach().to("cpu"))
+            sent[peer] = (k, send)
+            ops.append(dist.P2POp(dist.isend, msg[:cap + 1], peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, self._buffer(self.buf_in, peer, self.cap_in[peer] + 1)[:self.cap_in[peer] + 1],
+                                  peer, self.group))
+            self.bytes_sent += 4 * RECORD_WORDS * (cap + 1)
+        self._batch(ops)
+        heads = [self.buf_in[p][0, 0] for p, _ in peers if p is not None]
+        counts = [int(v) for v in torch.stack(heads).cpu().tolist()] if heads else []
+        got, more = {}, []
+        for (peer, _), k_in in zip([x for x in peers if x[0] is not None], counts):
+            cap = self.cap_in[peer]
+            got[peer] = [self.buf_in[peer][1:1 + min(k_in, cap)]]
+            if k_in > cap:  # the remainder follows, exactly k_in - cap records
+                rest = torch.empty((k_in - cap, RECORD_WORDS), dtype=torch.float32, device=self.device)
+                got[peer].append(rest)
+                more.append(dist.P2POp(dist.irecv, rest, peer, self.group))
+            self.cap_in[peer] = self._capacity_after(k_in)
+        for peer, (k, send) in sent.items():
+            cap = self.cap_out[peer]
+            if k > cap:
+                more.append(dist.P2POp(dist.isend, self._out(send[cap:]), peer, self.group))
+                self.bytes_sent += 4 * RECORD_WORDS * (k - cap)
+            self.cap_out[peer] = self._capacity_after(k)
+        self._batch(more)
+        empty = torch.empty((0, RECORD_WORDS), dtype=torch.float32, device=self.device)
+        out = []
+        for peer in (left, right):
+            parts = got.get(peer, [empty])
+            out.append(self._in(parts[0] if len(parts) == 1 else torch.cat(parts)))
+        return out[0], out[1]
+
+    def _exchange_two_rounds(self, send_left, send_right):
         torch, dist = self.torch, self.dist
         left, right = self._neighbours()
         # 1. counts (two ints per neighbour)
@@ -138,9 +214,7 @@ class DistExchange:
         if right is not None:
             ops.append(dist.P2POp(dist.isend, counts_out[1:2], right, self.group))
             ops.append(dist.P2POp(dist.irecv, from_right_n, right, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        self._batch(ops)
         nl, nr = int(from_left_n.item()), int(from_right_n.item())
         # 2. payload, exact sizes
         recv_left = torch.empty((nl, RECORD_WORDS), dtype=torch.float32, device=self.device)
@@ -151,14 +225,16 @@ class DistExchange:
                 ops.append(dist.P2POp(dist.isend, self._out(send_left), left, self.group))
             if nl:
                 ops.append(dist.P2POp(dist.irecv, recv_left, left, self.group))
+            self.cap_out[left] = self._capacity_after(send_left.shape[0])
+            self.cap_in[left] = self._capacity_after(nl)
         if right is not None:
             if send_right.shape[0]:
                 ops.append(dist.P2POp(dist.isend, self._out(send_right), right, self.group))
             if nr:
                 ops.append(dist.P2POp(dist.irecv, recv_right, right, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            self.cap_out[right] = self._capacity_after(send_right.shape[0])
+            self.cap_in[right] = self._capacity_after(nr)
+        self._batch(ops)
         self.bytes_sent += 4 * RECORD_WORDS * (send_left.shape[0] + send_right.shape[0])
         return self._in(recv_left), self._in(recv_right)
 
@@ -168,20 +244,19 @@ class DistExchange:
     def _in(self, t):
         return t if t.device == self.data_device else t.to(self.data_device)
 
-    def allreduce_max(self, value):
+    def allgather_histogram(self, local_hist, cuts, ncols, local_shift=0.0):
+        """Global per-column particle histogram from every rank's own-column counts, and the largest of the
+        ranks' column shifts, in ONE all-reduce: counts are summed into their columns, and every rank adds its
+        shift (in 1/1024 column) into a slot of its own behind them."""
         torch, dist = self.torch, self.dist
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
-
-    def allgather_histogram(self, local_hist, cuts, ncols):
-        """Global per-column particle histogram from every rank's own-column counts."""
-        torch, dist = self.torch, self.dist
-        full = torch.zeros(ncols, dtype=torch.int64, device=self.device)
+        full = torch.zeros(ncols + self.nranks, dtype=torch.int64)
         lo = cuts[self.rank]
-        full[lo:lo + len(local_hist)] = torch.as_tensor(np.asarray(local_hist, dtype=np.int64), device=self.device)
+        full[lo:lo + len(local_hist)] = torch.as_tensor(np.asarray(local_hist, dtype=np.int64))
+        full[ncols + self.rank] = int(np.ceil(float(local_shift) * 1024.0))
+        full = full.to(self.device)
         dist.all_reduce(full, group=self.group)
-        return full.cpu().numpy()
+        full = full.cpu().numpy()
+        return full[:ncols], float(full[ncols:].max()) / 1024.0
 
 
 # ---- per-rank driver ----------------------------------------------------------------------------------------
@@ -210,8 +285,8 @@ class SlabRunner:
 
     def rebalance(self):
         b = self.backend
-        hist = self.exchange.allgather_histogram(b.column_counts(), self.cuts, self.cuts[-1])
-        shift = self.exchange.allreduce_max(b.max_column_shift()) if hasattr(b, "max_column_shift") else 0.0
+        own_shift = b.max_column_shift() if hasattr(b, "max_column_shift") else 0.0
+        hist, shift = self.exchange.allgather_histogram(b.column_counts(), self.cuts, self.cuts[-1], own_shift)
         self.min_cols = min_columns_for_shift(shift)
         new = rebalance_cuts(self.cuts, hist, min_cols=self.min_cols)
         if new != self.cuts:

@@ -34,7 +34,10 @@ def main():
     b = OracleSlabBackend(orc, p, cuts[rank], cuts[rank + 1])
     m = (cols >= cuts[rank]) & (cols < cuts[rank + 1])
     b.upload(pos[m], vel[m], ids[m])
-    runner = slab.SlabRunner(b, slab.DistExchange(rank, world), rank, world, cuts, rebalance_every=2)
+    # argv[2] = "tight": messages sized with no headroom at all, so that most steps need the overflow round
+    tight = len(sys.argv) > 2 and sys.argv[2] == "tight"
+    ex = slab.DistExchange(rank, world, headroom=0.5, min_capacity=1) if tight else slab.DistExchange(rank, world)
+    runner = slab.SlabRunner(b, ex, rank, world, cuts, rebalance_every=2)
     nsteps = 8
     for _ in range(nsteps):
         runner.step()
@@ -48,7 +51,9 @@ def main():
             orc.step_grid(p, rp, rv, ids, order=0)
         ok = (np.array_equal(got[2], ids) and np.array_equal(got[0].view(np.uint32), rp.view(np.uint32))
               and np.array_equal(got[1].view(np.uint32), rv.view(np.uint32)))
-        print("cuts", cuts, "->", runner.cuts, "sent bytes", runner.exchange.bytes_sent)
+        print("cuts", cuts, "->", runner.cuts, "sent bytes", runner.exchange.bytes_sent, "rounds", runner.exchange.rounds)
+        # first step: counts + payload; afterwards one round per step unless a message outgrew its size
+        assert runner.exchange.rounds > nsteps + 1 if tight else runner.exchange.rounds == nsteps + 1
         print("BITWISE_MATCH" if ok else "MISMATCH")
         assert runner.cuts != cuts, "rebalancing never moved the cut"
     dist.barrier()

@@ -157,6 +157,99 @@ def test_particles_crossing_several_columns_per_step(oracle):
         b.close()
 
 
+class LoopbackDist:
+    """Stand-in for torch.distributed inside one process: ranks are threads, a send is a copy into the
+    matching receive's tensor.  Reports the "nccl" backend so that DistExchange takes its device-tensor path
+    (what runs over RCCL on a multi-GPU node), which a one-GPU box cannot reach through a real backend."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def wait(self):
+            pass
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, mail, lock, rank):
+        import threading
+        self.mail, self.lock, self.rank, self.threading = mail, lock, rank, threading
+
+    def get_backend(self, group=None):
+        return "nccl"
+
+    def batch_isend_irecv(self, ops):
+        import queue
+        for o in ops:
+            if o.op == "isend":
+                with self.lock:
+                    q = self.mail.setdefault((self.rank, o.peer), queue.Queue())
+                q.put(o.tensor.clone())
+        for o in ops:
+            if o.op == "irecv":
+                with self.lock:
+                    q = self.mail.setdefault((o.peer, self.rank), queue.Queue())
+                got = q.get(timeout=60)
+                assert got.shape == o.tensor.shape, "send and receive sizes must agree"
+                o.tensor.copy_(got)
+        return [self._Work() for _ in ops]
+
+
+@pytest.mark.parametrize("headroom,min_capacity", [(1.25, 1024), (0.5, 1)])
+def test_dist_exchange_device_path(oracle, headroom, min_capacity):
+    """Two slab contexts on one GPU driven by SlabRunner + DistExchange with device-resident record
+    tensors (loopback transport, one thread per rank): bit-identical to the single context, with the
+    one-round protocol and with its overflow round."""
+    import threading
+    import torch
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=16)
+    backends, cuts = make_slabs(p, pos, vel, ids, 2, oracle)
+    mail, lock = {}, threading.Lock()
+    dev = torch.device("cuda", 0)
+    runners = []
+    for r in range(2):
+        ex = slab.DistExchange.__new__(slab.DistExchange)
+        ex.torch, ex.dist = torch, LoopbackDist(mail, lock, r)
+        ex.rank, ex.nranks, ex.group = r, 2, None
+        ex.on_device, ex.device, ex.data_device = True, dev, dev
+        ex.bytes_sent = ex.rounds = 0
+        ex.headroom, ex.min_capacity = headroom, min_capacity
+        ex.cap_out, ex.cap_in, ex.buf_out, ex.buf_in = {}, {}, {}, {}
+        runners.append(slab.SlabRunner(backends[r], ex, r, 2, cuts, rebalance_every=0))
+    errors = []
+
+    def drive(runner):
+        try:
+            for _ in range(8):
+                runner.step()
+            runner.backend.sync()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in runners]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    with capi.Simulation(p, n_max=ids.size) as single:
+        single.upload(pos, vel)
+        single.step(8)
+        rp, rv = single.download()
+    got = by_id(*[np.concatenate(x) for x in zip(*[b.download() for b in backends])])
+    assert np.array_equal(got[2], ids)
+    assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
+    assert all(b.lost() == 0 for b in backends)
+    if min_capacity == 1:
+        assert runners[0].exchange.rounds > 9, "the tight sizing must have needed overflow rounds"
+    else:
+        assert runners[0].exchange.rounds == 9
+    for b in backends:
+        b.close()
+
+
 def test_record_capacity_error():
     p = default_params()
     pos, vel, ids = moving_block(n_side=10)

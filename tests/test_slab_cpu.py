@@ -168,11 +168,12 @@ def test_local_slabs_match_single_domain_bitwise(oracle, nslabs, rebalance):
 
 # ---- torch.distributed, gloo, world_size 2 -------------------------------------------------------------------
 
-def test_gloo_two_ranks_match_single_domain(tmp_path):
+@pytest.mark.parametrize("sizing", ["headroom", "tight"])
+def test_gloo_two_ranks_match_single_domain(tmp_path, sizing):
     script = os.path.join(ROOT, "tests", "slab_gloo_worker.py")
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + (7 if sizing == "tight" else 0)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, script, str(tmp_path)], env=dict(env, RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, script, str(tmp_path), sizing], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [pr.communicate(timeout=240)[0] for pr in procs]
     for r, pr in enumerate(procs):
