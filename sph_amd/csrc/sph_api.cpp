@@ -335,7 +335,7 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
     return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
   const size_t n = (size_t)n_max;
   if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n + kSearchOverread)) || (rc = dev_alloc(&c->sorted.rec, n)) ||
-      (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)kMaskWords * n)) ||
+      (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)(kMaskWords + 2) * n)) ||
       (rc = dev_alloc(&c->nmask.ncand, n)) || (rc = dev_alloc(&c->nmask.nnb, n)))
     return bail(rc);
   c->nmask.stride = n;

@@ -233,28 +233,24 @@ __device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count,
 // of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
 // current one is evaluated, so their latency hides behind the pair arithmetic.
 template <class Load, class Visit>
-__device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, const RunTable& rt, int col, Load load,
+__device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const RunTable& rt, int col, Load load,
                                  Visit visit) {
-  int words_left = (ncand + 31) >> 5;  // words not yet taken into m
-  const uint32_t* wp = nm.words + s;   // word after the one in m
+  if (nn <= 0) return;
+  // nn set bits are known to be there, so the walk needs no end-of-mask checks: the word after the current one
+  // is always fetched (the array has a spare row behind the last word) and next_index() always finds a bit.
+  const uint32_t* wp = nm.words + s;  // word after the one in m
   const size_t stride = nm.stride;
-  unsigned m = 0, m_next = 0;          // current word (bits still to visit), the word after it
-  if (words_left > 0) {
-    m = *wp;
-    wp += stride;
-    --words_left;
-  }
-  if (words_left > 0) m_next = *wp;
-  int qbase = 0;  // candidate index of bit 0 of the current word
+  unsigned m = *wp;  // current word (bits still to visit)
+  wp += stride;
+  unsigned m_next = *wp;  // the word after it
+  int qbase = 0;          // candidate index of bit 0 of the current word
   int k = 0, shift = rt.shift[0][col], qe = rt.qend[0][col];  // current run
-  auto next_index = [&]() -> int {  // index of the next set bit's candidate, -1 when the mask is exhausted
+  auto next_index = [&]() -> int {
     while (m == 0) {
-      if (words_left <= 0) return -1;
-      --words_left;
       qbase += 32;
       m = m_next;
       wp += stride;
-      m_next = words_left > 0 ? *wp : 0u;
+      m_next = *wp;
     }
     const int q = qbase + __ffs(m) - 1;
     m &= m - 1;
@@ -266,16 +262,14 @@ __device__ inline void walk_mask(const NeighbourMask& nm, int s, int ncand, cons
     return shift + q;
   };
   float4 pj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vj = pj, pn = pj, vn = pj;
-  int j = next_index();
-  if (j >= 0) load(j, pj, vj);
-  while (j >= 0) {
-    const int jn = next_index();
-    if (jn >= 0) load(jn, pn, vn);
+  load(next_index(), pj, vj);
+  for (int i = 1; i < nn; i++) {
+    load(next_index(), pn, vn);
     visit(pj, vj);
-    j = jn;
     pj = pn;
     vj = vn;
   }
+  visit(pj, vj);
 }
 
 // Calls visit(pos_j, vel_j) for every neighbour of particle slot s, in stencil order, from the mask written by
@@ -287,7 +281,7 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
                                           int col, Visit visit) {
   const int ncand = nm.ncand[s];
   if (ncand <= kMaskBits) {
-    walk_mask(nm, s, ncand, rt, col,
+    walk_mask(nm, s, nm.nnb[s], rt, col,
               [&](int j, float4& pj, float4& vj) {
                 if (WITH_VEL) {
                   pj = st.rec[j].pos;
