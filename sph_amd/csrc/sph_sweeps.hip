@@ -90,8 +90,9 @@ struct RunTable {
   int (*shift)[kBlock];  // first slot of run k minus the number of candidates before run k
   int (*qend)[kBlock];   // number of candidates up to and including run k
 };
-__device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
-                                 const RunTable& rt) {
+// Returns the number of kAhead-wide trips a walk over all runs takes.
+__device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
+                                const RunTable& rt) {
   const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
   // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
   // no branch, so that all 18 loads are issued before the first is waited for
@@ -104,15 +105,18 @@ __device__ inline void fill_runs(const DevParams& P, const int32_t* __restrict__
     b[k] = start[row + z0];
     e[k] = start[row + z1 + 1];
   }
-  int q = 0;
+  int q = 0, trips = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
     const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
+    const int len = inside ? e[k] - b[k] : 0;
     rt.shift[k][threadIdx.x] = b[k] - q;
-    q += inside ? e[k] - b[k] : 0;
+    q += len;
+    trips += (len + kAhead - 1) / kAhead;
     rt.qend[k][threadIdx.x] = q;
   }
+  return trips;
 }
 
 __device__ inline float dist2_to(const float4& a, const float4& b, float& dx, float& dy, float& dz) {
@@ -143,17 +147,17 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   const int s = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x + threadIdx.x;
   if (s >= hi) return;
   const float4 pi = st.pos[s];
-  fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
+  const int trips = fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
   unsigned word = 0;
   int q = 0, cnt = 0;  // q: candidates seen so far = index of the next one in the flattened stencil
   float dx, dy, dz;
+  // the number of trips is known up front, so the loop needs no end-of-stencil test: a trip always finds a run
   int k = -1, shift = 0, qe = 0;  // current run, its slot shift, its end in q
-  for (;;) {
-    if (q >= qe) {
-      if (++k >= 9) break;
+  for (int t = 0; t < trips; t++) {
+    while (q >= qe) {  // next non-empty run
+      ++k;
       shift = rt_shift[k][threadIdx.x];
       qe = rt_qend[k][threadIdx.x];
-      continue;
     }
     const int m = qe - q < kAhead ? qe - q : kAhead;
     // Always fetch kAhead consecutive slots from one base address: past the end of the run they belong to the
