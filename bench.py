@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--workload", default="dam_break", choices=["dam_break", "uniform_cube"])
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rebalance-every", type=int, default=4, help="multi-GPU: steps between cut-plane moves")
+    ap.add_argument("--rebalance-every", type=int, default=2, help="multi-GPU: steps between cut-plane moves")
     ap.add_argument("--cpu-sample-side", type=int, default=28,
                     help="CPU baseline runs the all-pairs reference algorithm on a side^3 sub-block")
     return ap.parse_args()
