@@ -229,6 +229,9 @@ int sph_slab_append(sph_context* ctx, const float* d_rec, int n_rec);
 
 /* Particles per OWN column at the last sort (host array, ncols = col_hi - col_lo entries). */
 int sph_slab_column_counts(sph_context* ctx, int32_t* counts, int capacity, int* ncols);
+/* sph_slab_column_counts and sph_slab_max_column_shift in one round trip to the device: what a load
+ * balancer asks for every time it runs. */
+int sph_slab_load_info(sph_context* ctx, int32_t* counts, int capacity, int* ncols, float* max_shift);
 /* Total number of RECEIVED records so far whose x-column lay outside this context's local grid (own
  * columns +- 2): particles that no context integrates any more.  Must stay 0; it cannot stay 0 when
  * particles cross more columns per step than the neighbouring slab is wide (see

@@ -53,6 +53,7 @@ _SIGNATURES = [
     ("sph_slab_column_counts", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("sph_slab_lost", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     ("sph_slab_max_column_shift", C.c_int, [_CTX, C.POINTER(C.c_float)]),
+    ("sph_slab_load_info", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
 ]
@@ -290,6 +291,14 @@ class SlabSimulation:
         v = C.c_int64()
         _check(self.lib.sph_slab_lost(self._ctx, C.byref(v)))
         return v.value
+
+    def load_info(self):
+        """(particles per own column at the last sort, max column shift): one device round trip."""
+        lo, hi, _ = self.columns()
+        out = np.empty(hi - lo, np.int32)
+        n, v = C.c_int(), C.c_float()
+        _check(self.lib.sph_slab_load_info(self._ctx, out.ctypes.data, out.size, C.byref(n), C.byref(v)))
+        return out, float(v.value)
 
     def max_column_shift(self):
         """Columns a particle can cross in the next step: max |vx| * dt / cell over this slab's particles."""

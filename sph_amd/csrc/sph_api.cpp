@@ -723,19 +723,37 @@ int sph_slab_append(sph_context* c, const float* d_rec, int n_rec) {
   return SPH_OK;
 }
 
-int sph_slab_column_counts(sph_context* c, int32_t* counts, int capacity, int* ncols) {
+// Column counts and (optionally) the column shift in one round trip to the device.
+static int load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, float* max_shift) {
   if (!c || !counts) return fail(SPH_ERR_INVALID, "NULL argument");
   if (!c->stepped) return fail(SPH_ERR_STATE, "column counts come from the last step's sort: step first");
   HIP_TRY(hipSetDevice(c->device));
   const int own = c->col_hi - c->col_lo;
   if (ncols) *ncols = own;
   if (own > capacity) return fail(SPH_ERR_CAPACITY, "%d own columns do not fit the caller's capacity %d", own, capacity);
+  if (max_shift) {
+    int rc = resolve_n(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_counters + 5, 0, sizeof(int32_t), c->stream));
+    launch_max_column_shift(c->stream, c->dev, c->cur, c->n, c->d_counters + 5);
+    HIP_TRY(hipMemcpyAsync(c->h_counters + 5, c->d_counters + 5, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  }
   launch_column_counts(c->stream, c->grid.start, c->dev.nx, c->dev.ny * c->dev.nz, c->d_colcounts);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(counts, c->d_colcounts + c->dev.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (max_shift) memcpy(max_shift, c->h_counters + 5, sizeof(float));
   return SPH_OK;
+}
+
+int sph_slab_column_counts(sph_context* c, int32_t* counts, int capacity, int* ncols) {
+  return load_info(c, counts, capacity, ncols, nullptr);
+}
+
+int sph_slab_load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, float* max_shift) {
+  if (!max_shift) return fail(SPH_ERR_INVALID, "NULL argument");
+  return load_info(c, counts, capacity, ncols, max_shift);
 }
 
 int sph_slab_lost(sph_context* c, int64_t* lost) {

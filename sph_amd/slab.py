@@ -285,8 +285,11 @@ class SlabRunner:
 
     def rebalance(self):
         b = self.backend
-        own_shift = b.max_column_shift() if hasattr(b, "max_column_shift") else 0.0
-        hist, shift = self.exchange.allgather_histogram(b.column_counts(), self.cuts, self.cuts[-1], own_shift)
+        if hasattr(b, "load_info"):
+            counts, own_shift = b.load_info()
+        else:
+            counts, own_shift = b.column_counts(), (b.max_column_shift() if hasattr(b, "max_column_shift") else 0.0)
+        hist, shift = self.exchange.allgather_histogram(counts, self.cuts, self.cuts[-1], own_shift)
         self.min_cols = min_columns_for_shift(shift)
         new = rebalance_cuts(self.cuts, hist, min_cols=self.min_cols)
         if new != self.cuts:

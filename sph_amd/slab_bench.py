@@ -26,6 +26,8 @@ def main(args):
                          f"got WORLD_SIZE={world}")
     shared_gpu = os.environ.get("SPH_BENCH_SHARED_GPU") == "1"  # rehearsal: all ranks on GPU 0, gloo transport
     dev_index = 0 if shared_gpu else local
+    if shared_gpu:
+        torch.set_num_threads(1)  # host-staged records: many ranks' intra-op thread pools would fight for the cores
     torch.cuda.set_device(dev_index)
     dist.init_process_group("gloo" if shared_gpu else "nccl", rank=rank, world_size=world)
     device = torch.device("cuda", dev_index)
