@@ -50,7 +50,7 @@ enum {
    * sph_download_debug (costs 16 B/particle of extra stores per step). */
   SPH_FLAG_KEEP_DEBUG = 1u << 2,
   /* Ablation switch for the density and force passes; results are the same bit for bit.
-   * LANE_SWEEP: plain one-lane-per-particle sweep without neighbour queues. */
+   * LANE_SWEEP: plain one-lane-per-particle sweep: distance test and pair arithmetic in one loop, no candidate mask. */
   SPH_FLAG_LANE_SWEEP = 1u << 3
 };
 
