@@ -210,6 +210,10 @@ def main():
             out["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_force", "achieved": insts / force_s, "peak": peak,
                                     "unit": "wave-instructions/s", "frac": insts / force_s / peak,
                                     "wave_insts_per_launch": insts}
+        step_bytes = sum(BYTES_PER_PARTICLE.values()) - BYTES_PER_PARTICLE["search"]  # the 140 B pipeline model
+        whole = step_bytes * n / (dt / steps) / 1e9
+        out["roofline_step"] = {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": whole / HBM_PEAK_GBS, "bytes_per_particle": step_bytes}
         out["kernel_ms_per_step"] = per
     if not args.no_cpu_baseline and rank == 0:
         out["cpu_baseline"] = cpu_baseline(args)
