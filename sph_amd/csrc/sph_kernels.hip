@@ -160,10 +160,13 @@ __global__ void __launch_bounds__(kBlock) k_scan_top(int32_t* __restrict__ block
   }
 }
 
-// Writes start[] and leaves count[] zeroed for the next step's histogram.
+// Writes start[] and leaves count[] zeroed for the next step's histogram.  With sums_are_raw the per-block sums
+// have not been through k_scan_top: every block adds up the sums of the blocks before it itself (a few KB from
+// L2 on grids of up to kFusedTopBlocks tiles), which saves a launch whose single block only waits on memory.
+constexpr int kFusedTopBlocks = 2048;
 __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ count, size_t ncells,
                                                        const int32_t* __restrict__ block_sums,
-                                                       int32_t* __restrict__ start) {
+                                                       int32_t* __restrict__ start, int sums_are_raw) {
   size_t base = (size_t)blockIdx.x * kScanItems + (size_t)threadIdx.x * kPerThread;
   int v[kPerThread];
   int s = 0;
@@ -186,7 +189,15 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ cou
 #pragma unroll
   for (int k = 0; k < kPerThread; k++) s += v[k];
   int tot;
-  int run = block_sums[blockIdx.x] + block_exclusive_scan(s, &tot);
+  int before;
+  if (sums_are_raw) {
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) part += block_sums[b];
+    block_exclusive_scan(part, &before);
+  } else {
+    before = block_sums[blockIdx.x];
+  }
+  int run = before + block_exclusive_scan(s, &tot);
   if (full) {
     int4* o = reinterpret_cast<int4*>(start + base);
 #pragma unroll
@@ -374,8 +385,10 @@ void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, Grid
 void launch_scan(hipStream_t s, GridBuffers g) {
   int nb = (int)g.scan_blocks;
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, g.block_sums, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start);
+  const bool fused = nb <= kFusedTopBlocks;
+  if (!fused) hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, g.block_sums, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start,
+                     fused ? 1 : 0);
 }
 
 void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g) {

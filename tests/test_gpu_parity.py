@@ -230,6 +230,25 @@ def test_crowded_cells(oracle, n, spread):
     assert max_rel(gp, pa) <= TOL_ONE_STEP
 
 
+def test_few_particles_in_a_large_grid(oracle):
+    """A 2.1 m tank is 210 cells per side, 9.3M cells (more than 2048 scan tiles: the prefix sum takes its
+    three-kernel route), nearly all of them empty; the block sits far from the origin."""
+    pos, vel = scenes.jittered_lattice(10, 10, 10, origin=(1.7, 0.4, 1.9), seed=9)
+    p = default_params(flags=DBG)
+    p.tank_size = 2.1
+    po, vo = pos.copy(), vel.copy()
+    with capi.Simulation(p, n_max=pos.shape[0]) as sim:
+        assert sim.grid_dims() == (210, 210, 210)
+        sim.upload(pos, vel)
+        for _ in range(3):
+            rho_o, f_o, nc_o = oracle.step_grid(p, po, vo, order=0, want_debug=True)
+            sim.step(1)
+            rho, f, nc, _ = sim.download_debug()
+            assert np.array_equal(nc, nc_o) and bits_equal(rho, rho_o) and bits_equal(f, f_o)
+        gp, gv = sim.download()
+    assert bits_equal(gp, po) and bits_equal(gv, vo)
+
+
 def test_particles_outside_the_tank(oracle):
     """Positions beyond the walls are legal inputs for the reference (all-pairs); cell indices
     clamp, which only merges cells, so the stencil still covers every neighbour pair."""
