@@ -221,7 +221,11 @@ int sph_slab_download_debug(sph_context* ctx, float* rho, float* force, int32_t*
                             int32_t* cell, int capacity);
 
 /* Fill the caller's DEVICE buffers (capacity records each) with the records the left / right
- * neighbour needs; counts come back on the host.  Pass NULL for a face at the tank wall. */
+ * neighbour needs; counts come back on the host.  Pass NULL for a face at the tank wall.
+ * After the first call a context packs these records right behind every step (into buffers of its
+ * own, counts travelling home with the particle count), so that the call between two steps is a
+ * copy instead of a kernel and a second round trip; anything that changes the particle set or the
+ * cut planes in between makes it pack on demand again. */
 int sph_slab_pack(sph_context* ctx, float* d_rec_left, float* d_rec_right, int capacity,
                   int* n_left, int* n_right);
 /* Add n_rec records from a DEVICE buffer to the particle set. */

@@ -31,6 +31,8 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SPH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+constexpr size_t kRecordBytes = SPH_SLAB_RECORD_WORDS * sizeof(float);
+
 enum Cat { CAT_HASH, CAT_SCAN, CAT_REORDER, CAT_SEARCH, CAT_DENSITY, CAT_FORCE, CAT_OTHER, CAT_N };
 
 struct EventPair {
@@ -66,6 +68,12 @@ struct sph_context {
   int32_t* h_counters = nullptr;      // pinned mirror
   int32_t* d_colcounts = nullptr;     // [cols_capacity + 4]
   bool n_pending = false;             // true count of `cur` still travelling to h_counters[2]
+  // Records for the neighbours, packed right behind the force pass of a step into buffers of the context's own
+  // (the counts travel home with the own count): the next sph_slab_pack then only copies them out.
+  float* pre_rec[2] = {nullptr, nullptr};
+  int pre_cap = 0;
+  bool pre_side[2] = {false, false};  // which faces the caller packs for (as of its last sph_slab_pack)
+  bool pre_valid = false;             // pre_rec and h_counters[0..1] describe the current `cur` and cuts
   int64_t lost = 0;
   bool timing = false;
   std::vector<EventPair> pending;
@@ -213,6 +221,7 @@ void free_state(State* s) {
 }
 
 int set_grid(sph_context* c, const sph_params* p, int col_lo, int col_hi) {
+  c->pre_valid = false;  // packed for the old cut planes / cell size
   int gn = cells_per_axis(p);
   if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
   if (!c->slab) { col_lo = 0; col_hi = gn; }
@@ -277,8 +286,16 @@ int one_step(sph_context* c) {
   c->dbg_stride = n;
   if (c->slab) {
     // ghosts and emigrants drop out here: only own-column particles were written back
-    HIP_TRY(hipMemcpyAsync(c->h_counters + 2, c->d_counters + 2, 3 * sizeof(int32_t), hipMemcpyDeviceToHost,
-                           c->stream));
+    c->pre_valid = false;
+    if (c->pre_cap > 0) {
+      const bool has_left = c->col_lo > 0 && c->pre_side[0], has_right = c->col_hi < c->gn && c->pre_side[1];
+      HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
+      Timed t(c, CAT_OTHER);
+      launch_slab_pack(c->stream, c->dev, c->cur, n, c->d_counters + 2, c->col_lo, c->col_hi, has_left, has_right,
+                       c->pre_rec[0], c->pre_rec[1], c->pre_cap, c->d_counters);
+      c->pre_valid = true;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     c->n_pending = true;
   } else {
     int32_t* t = c->cur.id;
@@ -412,6 +429,7 @@ int sph_destroy(sph_context* c) {
   (void)hipFree(c->dbg.force); (void)hipFree(c->dbg.ncount);
   (void)hipFree(c->stage_pos); (void)hipFree(c->stage_vel); (void)hipFree(c->stage_dbg);
   (void)hipFree(c->d_counters); (void)hipFree(c->d_colcounts);
+  (void)hipFree(c->pre_rec[0]); (void)hipFree(c->pre_rec[1]);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -448,6 +466,7 @@ static int upload_common(sph_context* c, const float* pos, const float* vel, int
   c->n_pending = false;
   c->uploaded = true;
   c->stepped = false;
+  c->pre_valid = false;
   return SPH_OK;
 }
 
@@ -625,6 +644,7 @@ int sph_slab_upload(sph_context* c, const float* pos, const float* vel, const in
   c->n_pending = false;
   c->uploaded = true;
   c->stepped = false;
+  c->pre_valid = false;
   return SPH_OK;
 }
 
@@ -687,11 +707,30 @@ int sph_slab_pack(sph_context* c, float* d_left, float* d_right, int capacity, i
   int rc = resolve_n(c);
   if (rc) return rc;
   const bool has_left = c->col_lo > 0 && d_left, has_right = c->col_hi < c->gn && d_right;
+  const bool same_request = c->pre_cap == capacity && c->pre_side[0] == (d_left != nullptr) &&
+                            c->pre_side[1] == (d_right != nullptr);
+  if (c->pre_valid && same_request) {
+    // packed behind the last step: the counts came home with the own count, the records are copied out
+    c->pre_valid = false;
+    *n_left = c->h_counters[0];
+    *n_right = c->h_counters[1];
+    if (*n_left > capacity || *n_right > capacity)
+      return fail(SPH_ERR_CAPACITY, "halo/migration records (%d left, %d right) exceed the buffer capacity %d",
+                  *n_left, *n_right, capacity);
+    const size_t rec = kRecordBytes;
+    if (*n_left > 0)
+      HIP_TRY(hipMemcpyAsync(d_left, c->pre_rec[0], (size_t)*n_left * rec, hipMemcpyDeviceToDevice, c->stream));
+    if (*n_right > 0)
+      HIP_TRY(hipMemcpyAsync(d_right, c->pre_rec[1], (size_t)*n_right * rec, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+  }
+  c->pre_valid = false;
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
   {
     Timed t(c, CAT_OTHER);
-    launch_slab_pack(c->stream, c->dev, c->cur, c->n, c->col_lo, c->col_hi, has_left, has_right, d_left, d_right,
-                     capacity, c->d_counters);
+    launch_slab_pack(c->stream, c->dev, c->cur, c->n, nullptr, c->col_lo, c->col_hi, has_left, has_right, d_left,
+                     d_right, capacity, c->d_counters);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -701,6 +740,26 @@ int sph_slab_pack(sph_context* c, float* d_left, float* d_right, int capacity, i
   if (*n_left > capacity || *n_right > capacity)
     return fail(SPH_ERR_CAPACITY, "halo/migration records (%d left, %d right) exceed the buffer capacity %d", *n_left,
                 *n_right, capacity);
+  // from now on the records of the next exchange are packed right behind each step
+  if (!same_request && capacity > 0) {
+    for (auto& p : c->pre_rec) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+    c->pre_cap = 0;
+    if (hipMalloc((void**)&c->pre_rec[0], (size_t)capacity * kRecordBytes) == hipSuccess &&
+        hipMalloc((void**)&c->pre_rec[1], (size_t)capacity * kRecordBytes) == hipSuccess) {
+      c->pre_cap = capacity;
+      c->pre_side[0] = d_left != nullptr;
+      c->pre_side[1] = d_right != nullptr;
+    } else {
+      (void)hipGetLastError();  // no room for the shortcut: keep packing on demand
+      for (auto& p : c->pre_rec) {
+        (void)hipFree(p);
+        p = nullptr;
+      }
+    }
+  }
   return SPH_OK;
 }
 
@@ -720,6 +779,7 @@ int sph_slab_append(sph_context* c, const float* d_rec, int n_rec) {
   HIP_TRY(hipGetLastError());
   c->n += n_rec;
   c->uploaded = true;
+  if (n_rec > 0) c->pre_valid = false;
   return SPH_OK;
 }
 

@@ -97,8 +97,9 @@ void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, 
 void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,
                   const GridBuffers& g, float* force_dbg, int32_t* n_own_out, const NeighbourMask& nm,
                   SweepMode mode);
-void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
-                      bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters);
+void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, const int32_t* n_dev, int col_lo,
+                      int col_hi, bool has_left, bool has_right, float* rec_left, float* rec_right, int cap,
+                      int32_t* counters);
 void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int n_rec, const State& st, int at,
                         int32_t* stray);
 void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out);

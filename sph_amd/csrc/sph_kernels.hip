@@ -259,11 +259,12 @@ constexpr int kRecWords = 7;
 
 // Every particle whose x-column is within two columns of (or beyond) a slab face is copied to the buffer
 // for the neighbour behind that face: it is either a migrant (new owner: the neighbour) or a ghost for it.
-__global__ void k_slab_pack(DevParams P, State st, int n, int col_lo, int col_hi, int has_left, int has_right,
-                            float* __restrict__ rec_left, float* __restrict__ rec_right, int cap,
-                            int32_t* __restrict__ counters) {
+// n_dev, when given, holds the true particle count on the device (the launch then covers an upper bound n).
+__global__ void k_slab_pack(DevParams P, State st, int n, const int32_t* __restrict__ n_dev, int col_lo, int col_hi,
+                            int has_left, int has_right, float* __restrict__ rec_left,
+                            float* __restrict__ rec_right, int cap, int32_t* __restrict__ counters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (n_dev ? *n_dev : n)) return;
   int g = cell_coord(st.x[i], P.cell, P.gnx);
   bool to_left = has_left && g < col_lo + 2;
   bool to_right = has_right && g >= col_hi - 2;
@@ -399,10 +400,11 @@ void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, Gr
                      g.src_of, g.id_prov, g.cell_s);
 }
 
-void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, int col_lo, int col_hi,
-                      bool has_left, bool has_right, float* rec_left, float* rec_right, int cap, int32_t* counters) {
+void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, const int32_t* n_dev, int col_lo,
+                      int col_hi, bool has_left, bool has_right, float* rec_left, float* rec_right, int cap,
+                      int32_t* counters) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_slab_pack, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, col_lo, col_hi,
+  hipLaunchKernelGGL(k_slab_pack, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, n_dev, col_lo, col_hi,
                      has_left ? 1 : 0, has_right ? 1 : 0, rec_left, rec_right, cap, counters);
 }
 
