@@ -166,6 +166,23 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
                          int num_particles);
 
 /*
+ * The same step for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  (No counterpart in the reference, whose updateParticles mallocs
+ * its temporaries on every call, compute.cpp:122,128.)  One updateParticles on DEVICE arrays of
+ * 3*num_particles floats each, advanced in place, issued on `stream` (a hipStream_t; NULL = the null
+ * stream) of the CURRENT device and not waited for.  The call allocates and frees nothing: every
+ * intermediate buffer is a piece of one static device array inside the library
+ * (about 14 MB, held by each GPU the library runs on until the process ends), which bounds the input:
+ * at most SPH_NOALLOC_MAX_PARTICLES particles and SPH_NOALLOC_MAX_CELLS grid cells
+ * (SPH_ERR_CAPACITY beyond); SPH_FLAG_KEEP_DEBUG is rejected.  All calls on one GPU share that
+ * array: calls that overlap in time on the same GPU (different streams or threads) race.
+ */
+#define SPH_NOALLOC_MAX_PARTICLES 32768
+#define SPH_NOALLOC_MAX_CELLS 262144 /* 64^3: a tank of up to 64 cell edges per axis */
+int sph_update_particles_noalloc(const sph_params* params, float* d_particles, float* d_velocities,
+                                 int num_particles, void* stream);
+
+/*
  * Counterpart of initParticles' fill (compute.cpp:106-117): uniform random block in
  * [0, tank/2]^3 from a 64-bit LCG seeded with `seed`, zero velocities, written to host arrays
  * the caller owns.  (The reference seeds glibc rand() with time(0), which is not reproducible;

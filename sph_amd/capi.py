@@ -39,6 +39,7 @@ _SIGNATURES = [
     ("sph_get_timings", C.c_int, [_CTX, C.POINTER(SphTimings)]),
     ("sph_reset_timings", C.c_int, [_CTX]),
     ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_update_particles_noalloc", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("sph_fill_random_block", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     # slab decomposition
     ("sph_global_cells", C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -58,6 +59,8 @@ _SIGNATURES = [
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
 ]
 
+NOALLOC_MAX_PARTICLES = 32768  # SPH_NOALLOC_MAX_PARTICLES
+NOALLOC_MAX_CELLS = 262144     # SPH_NOALLOC_MAX_CELLS
 RECORD_WORDS = 7      # SPH_SLAB_RECORD_WORDS: x, y, z, vx, vy, vz, id
 MIN_SLAB_COLUMNS = 4  # SPH_SLAB_MIN_COLUMNS
 
@@ -350,6 +353,13 @@ def update_particles(pos, vel, params=None):
     assert pos.dtype == np.float32 and vel.dtype == np.float32 and pos.flags.c_contiguous and vel.flags.c_contiguous
     _check(lib.sph_update_particles(C.byref(params) if params is not None else None, pos.ctypes.data,
                                     vel.ctypes.data, pos.size // 3))
+
+
+def update_particles_noalloc(d_pos_ptr, d_vel_ptr, n, params=None, stream_ptr=None):
+    """updateParticles on DEVICE arrays, in place, without any allocation; asynchronous on `stream_ptr`."""
+    lib = load()
+    _check(lib.sph_update_particles_noalloc(C.byref(params) if params is not None else None, C.c_void_p(d_pos_ptr),
+                                            C.c_void_p(d_vel_ptr), int(n), C.c_void_p(stream_ptr)))
 
 
 def fill_random_block(n, params=None, seed=1):

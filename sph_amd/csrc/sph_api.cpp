@@ -194,22 +194,56 @@ void derive(const sph_params* p, int nx, int cx_off, int gn, DevParams* d) {
   d->tension = (p->flags & SPH_FLAG_SURFACE_TENSION) ? 1 : 0;
 }
 
-template <class T>
-int dev_alloc(T** p, size_t count) {
+// Where a context's device buffers come from: one hipMalloc each (sph_create), or consecutive 256-byte-aligned
+// pieces of a region that already exists (the no-allocation entry point).
+struct MallocSource {
+  int take(void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 1));
+    return SPH_OK;
+  }
+};
+struct RegionSource {
+  unsigned char* base;
+  size_t size, used = 0;
+  RegionSource(void* b, size_t s) : base((unsigned char*)b), size(s) {}
+  int take(void** p, size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (at + bytes > size) return fail(SPH_ERR_CAPACITY, "device region of %zu bytes is too small", size);
+    *p = base + at;
+    used = at + bytes;
+    return SPH_OK;
+  }
+};
+
+template <class Source, class T>
+int dev_alloc(Source& src, T** p, size_t count) {
   *p = nullptr;
-  HIP_TRY(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
-  return SPH_OK;
+  return src.take((void**)p, (count ? count : 1) * sizeof(T));
 }
 
-int alloc_state(State* s, size_t n) {
+// Cells of a context's tables, rounded up to whole scan tiles (the scan kernels move int4s).
+size_t padded_cells(size_t ncells) { return ((ncells + kScanItems - 1) / kScanItems) * kScanItems; }
+
+// Every device buffer one step touches, for n particles and ncells cells.
+template <class Source>
+int layout_step_buffers(Source& src, sph_context* c, size_t n, size_t ncells) {
   int rc;
-  if ((rc = dev_alloc(&s->x, n))) return rc;
-  if ((rc = dev_alloc(&s->y, n))) return rc;
-  if ((rc = dev_alloc(&s->z, n))) return rc;
-  if ((rc = dev_alloc(&s->vx, n))) return rc;
-  if ((rc = dev_alloc(&s->vy, n))) return rc;
-  if ((rc = dev_alloc(&s->vz, n))) return rc;
-  if ((rc = dev_alloc(&s->id, n))) return rc;
+  State* s = &c->cur;
+  if ((rc = dev_alloc(src, &s->x, n)) || (rc = dev_alloc(src, &s->y, n)) || (rc = dev_alloc(src, &s->z, n)) ||
+      (rc = dev_alloc(src, &s->vx, n)) || (rc = dev_alloc(src, &s->vy, n)) || (rc = dev_alloc(src, &s->vz, n)) ||
+      (rc = dev_alloc(src, &s->id, n)))
+    return rc;
+  if ((rc = dev_alloc(src, &c->sorted.pos, n + kSearchOverread)) || (rc = dev_alloc(src, &c->sorted.rec, n)) ||
+      (rc = dev_alloc(src, &c->sorted.id, n)) || (rc = dev_alloc(src, &c->nmask.words, (size_t)(kMaskWords + 2) * n)) ||
+      (rc = dev_alloc(src, &c->nmask.ncand, n)) || (rc = dev_alloc(src, &c->nmask.nnb, n)))
+    return rc;
+  c->nmask.stride = n;
+  const size_t padded = padded_cells(ncells);
+  if ((rc = dev_alloc(src, &c->grid.count, padded)) || (rc = dev_alloc(src, &c->grid.start, padded + 4)) ||
+      (rc = dev_alloc(src, &c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(src, &c->grid.cell_of, n)) ||
+      (rc = dev_alloc(src, &c->grid.rank_of, n)) || (rc = dev_alloc(src, &c->grid.src_of, n)) ||
+      (rc = dev_alloc(src, &c->grid.id_prov, n)) || (rc = dev_alloc(src, &c->grid.cell_s, n)))
+    return rc;
   return SPH_OK;
 }
 
@@ -351,21 +385,13 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipStreamCreate failed"));
   const size_t n = (size_t)n_max;
-  if ((rc = alloc_state(&c->cur, n)) || (rc = dev_alloc(&c->sorted.pos, n + kSearchOverread)) || (rc = dev_alloc(&c->sorted.rec, n)) ||
-      (rc = dev_alloc(&c->sorted.id, n)) || (rc = dev_alloc(&c->nmask.words, (size_t)(kMaskWords + 2) * n)) ||
-      (rc = dev_alloc(&c->nmask.ncand, n)) || (rc = dev_alloc(&c->nmask.nnb, n)))
-    return bail(rc);
-  c->nmask.stride = n;
-  // scan kernels read/write whole 4096-cell tiles through int4: round the tables up to a tile
-  size_t padded = ((ncells + kScanItems - 1) / kScanItems) * kScanItems;
-  if ((rc = dev_alloc(&c->grid.count, padded)) || (rc = dev_alloc(&c->grid.start, padded + 4)) ||
-      (rc = dev_alloc(&c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(&c->grid.cell_of, n)) ||
-      (rc = dev_alloc(&c->grid.rank_of, n)) || (rc = dev_alloc(&c->grid.src_of, n)) ||
-      (rc = dev_alloc(&c->grid.id_prov, n)) || (rc = dev_alloc(&c->grid.cell_s, n)) ||
-      (rc = dev_alloc(&c->dbg.force, 3 * n)) ||
-      (rc = dev_alloc(&c->dbg.ncount, n)) || (rc = dev_alloc(&c->stage_pos, 3 * n)) ||
-      (rc = dev_alloc(&c->stage_vel, 3 * n)) || (rc = dev_alloc((uint32_t**)&c->stage_dbg, 6 * n)) ||
-      (rc = dev_alloc(&c->d_counters, 8)) || (rc = dev_alloc(&c->d_colcounts, (size_t)cap_cols + 4)))
+  MallocSource heap;
+  if ((rc = layout_step_buffers(heap, c, n, ncells))) return bail(rc);
+  const size_t padded = padded_cells(ncells);
+  if ((rc = dev_alloc(heap, &c->dbg.force, 3 * n)) || (rc = dev_alloc(heap, &c->dbg.ncount, n)) ||
+      (rc = dev_alloc(heap, &c->stage_pos, 3 * n)) || (rc = dev_alloc(heap, &c->stage_vel, 3 * n)) ||
+      (rc = dev_alloc(heap, (uint32_t**)&c->stage_dbg, 6 * n)) || (rc = dev_alloc(heap, &c->d_counters, 8)) ||
+      (rc = dev_alloc(heap, &c->d_colcounts, (size_t)cap_cols + 4)))
     return bail(rc);
   if (hipHostMalloc((void**)&c->h_counters, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipHostMalloc failed"));
@@ -883,6 +909,90 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
   if ((rc = sph_upload(g_default, particles, velocities, num_particles))) return rc;
   if ((rc = sph_step(g_default, 1))) return rc;
   return sph_download(g_default, particles, velocities);
+}
+
+// ---- one-call step that allocates nothing -------------------------------------------------------------------
+// Same step as sph_update_particles, for callers that cannot allocate device memory (HIP graph capture, tight
+// serving loops, harnesses that forbid hipMalloc).  Every intermediate buffer of the step - SoA state, grid-sorted
+// copies, neighbour masks, cell tables - is a piece of ONE file-scope device array, `scratch`, sized for
+// SPH_NOALLOC_MAX_PARTICLES particles and SPH_NOALLOC_MAX_CELLS cells.  In host code the array's name is only a
+// handle: its device address on each GPU comes from hipGetSymbolAddress, once per device, and that pointer is what
+// kernels and memsets are given.
+constexpr size_t kNoAllocCells = (size_t)SPH_NOALLOC_MAX_CELLS + 1;  // + trash cell
+constexpr size_t kNoAllocPerParticle =
+    7 * 4 + sizeof(float4) + sizeof(ParticleRec) + 4 + (size_t)(kMaskWords + 2) * 4 + 2 * 4 + 5 * 4;
+constexpr size_t kNoAllocPerCell = 2 * sizeof(int32_t);
+constexpr size_t kScratchBytes = kNoAllocPerParticle * SPH_NOALLOC_MAX_PARTICLES +
+                                 kNoAllocPerCell * (kNoAllocCells + 2 * kScanItems) + 64 * 1024;  // + alignment slack
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+struct NoAllocSlot {
+  bool ready = false;
+  void* base = nullptr;  // device address of `scratch` on this GPU
+  sph_context ctx;
+};
+NoAllocSlot g_noalloc[kMaxDevices];
+std::mutex g_noalloc_mu;
+}  // namespace
+
+int sph_update_particles_noalloc(const sph_params* params, float* d_particles, float* d_velocities,
+                                 int num_particles, void* stream) {
+  sph_params p;
+  if (params) p = *params; else sph_params_default(&p);
+  int rc = check_params(&p);
+  if (rc) return rc;
+  if (num_particles < 0) return fail(SPH_ERR_INVALID, "num_particles < 0");
+  if (num_particles > SPH_NOALLOC_MAX_PARTICLES)
+    return fail(SPH_ERR_CAPACITY, "%d particles exceed the %d this entry point's fixed scratch holds", num_particles,
+                SPH_NOALLOC_MAX_PARTICLES);
+  if (p.flags & SPH_FLAG_KEEP_DEBUG)
+    return fail(SPH_ERR_INVALID, "SPH_FLAG_KEEP_DEBUG needs buffers this entry point does not have");
+  const int gn = cells_per_axis(&p);
+  if (gn < 0 || (size_t)gn * gn * gn > (size_t)SPH_NOALLOC_MAX_CELLS)
+    return fail(SPH_ERR_CAPACITY, "a tank of %g with cells of %g needs more than the %d cells this entry point's fixed scratch holds",
+                p.tank_size, resolved_cell(&p), SPH_NOALLOC_MAX_CELLS);
+  if (num_particles == 0) return SPH_OK;
+  if (!d_particles || !d_velocities) return fail(SPH_ERR_INVALID, "particles/velocities pointer is NULL");
+
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(SPH_ERR_NO_DEVICE, "device %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  NoAllocSlot& slot = g_noalloc[dev];
+  sph_context* c = &slot.ctx;
+  if (!slot.ready) {
+    // once per device, with that device current: where this GPU keeps its copy of the array
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(SPH_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", dev, prop.gcnArchName);
+    void* base = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&base, HIP_SYMBOL(scratch)));
+    if (!base) return fail(SPH_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    RegionSource region(base, kScratchBytes);
+    if ((rc = layout_step_buffers(region, c, (size_t)SPH_NOALLOC_MAX_PARTICLES, kNoAllocCells))) return rc;
+    c->device = dev;
+    c->n_max = SPH_NOALLOC_MAX_PARTICLES;
+    c->cell_capacity = kNoAllocCells;
+    c->own_stream = false;
+    slot.base = base;
+    slot.ready = true;
+  }
+  c->stream = (hipStream_t)stream;
+  if ((rc = set_grid(c, &p, 0, 0))) return rc;
+  // The array keeps the last call's contents.  The one table a step expects zeroed is the cell histogram (a step
+  // leaves it zeroed behind itself, but a call that failed half-way or a different grid would not have).
+  HIP_TRY(hipMemsetAsync(c->grid.count, 0, padded_cells(c->grid.ncells) * sizeof(int32_t), c->stream));
+  launch_split_aos(c->stream, d_particles, d_velocities, num_particles, c->cur);
+  c->n = num_particles;
+  c->n_pending = false;
+  c->uploaded = true;
+  if ((rc = one_step(c))) return rc;
+  launch_gather_aos(c->stream, c->cur, num_particles, d_particles, d_velocities);
+  HIP_TRY(hipGetLastError());
+  return SPH_OK;
 }
 
 int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos, float* vel, int n) {
