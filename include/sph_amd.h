@@ -120,7 +120,8 @@ int sph_get_params(const sph_context* ctx, sph_params* params);
 
 /* Host -> HBM.  pos_aos/vel_aos: float[3*n] in caller order; particle i gets id i. */
 int sph_upload(sph_context* ctx, const float* pos_aos, const float* vel_aos, int n);
-/* Same, from device pointers (HBM-resident inputs; no PCIe traffic). */
+/* Same, from device pointers (HBM-resident inputs; no PCIe traffic).  Read on the context's stream: see
+ * sph_stream_wait when another stream wrote them. */
 int sph_upload_device(sph_context* ctx, const float* d_pos_aos, const float* d_vel_aos, int n);
 
 /*
@@ -245,7 +246,8 @@ int sph_slab_download_debug(sph_context* ctx, float* rho, float* force, int32_t*
  * cut planes in between makes it pack on demand again. */
 int sph_slab_pack(sph_context* ctx, float* d_rec_left, float* d_rec_right, int capacity,
                   int* n_left, int* n_right);
-/* Add n_rec records from a DEVICE buffer to the particle set. */
+/* Add n_rec records from a DEVICE buffer to the particle set.  Read on the context's stream: see sph_stream_wait
+ * when another stream (the transport's) wrote them. */
 int sph_slab_append(sph_context* ctx, const float* d_rec, int n_rec);
 
 /* Particles per OWN column at the last sort (host array, ncols = col_hi - col_lo entries). */
@@ -269,6 +271,12 @@ int sph_slab_max_column_shift(sph_context* ctx, float* columns);
  * orders its transfers against). */
 int sph_get_stream(sph_context* ctx, void** stream);
 int sph_set_stream(sph_context* ctx, void* stream);
+/* Device buffers handed to sph_upload_device / sph_slab_append are read on the context's stream.  When another
+ * stream produced them (a communication library's, a framework's), the caller must order the two: this call
+ * makes everything the context issues from now on wait for the work submitted to producer_stream so far
+ * (event record + stream wait, no host synchronisation).  The other direction needs nothing: sph_download_device
+ * and sph_slab_pack return only when their output is complete. */
+int sph_stream_wait(sph_context* ctx, void* producer_stream);
 
 #ifdef __cplusplus
 }

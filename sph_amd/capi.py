@@ -57,6 +57,7 @@ _SIGNATURES = [
     ("sph_slab_load_info", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
+    ("sph_stream_wait", C.c_int, [_CTX, C.c_void_p]),
 ]
 
 NOALLOC_MAX_PARTICLES = 32768  # SPH_NOALLOC_MAX_PARTICLES
@@ -164,7 +165,10 @@ class Simulation:
         assert vel.size == pos.size
         _check(self.lib.sph_upload(self._ctx, pos.ctypes.data, vel.ctypes.data, n))
 
-    def upload_device(self, d_pos_ptr, d_vel_ptr, n):
+    def upload_device(self, d_pos_ptr, d_vel_ptr, n, producer_stream=None):
+        """producer_stream: the stream that wrote the buffers (a hipStream_t as int); the context waits for it."""
+        if producer_stream is not None:
+            _check(self.lib.sph_stream_wait(self._ctx, C.c_void_p(producer_stream)))
         _check(self.lib.sph_upload_device(self._ctx, C.c_void_p(d_pos_ptr), C.c_void_p(d_vel_ptr), int(n)))
 
     def step(self, nsteps=1):
@@ -253,11 +257,10 @@ class SlabSimulation:
         _check(self.lib.sph_slab_set_columns(self._ctx, int(lo), int(hi)))
 
     def column_counts(self):
-        lo, hi, _ = self.columns()
-        out = np.empty(hi - lo, np.int32)
+        out = np.empty(self.columns()[2], np.int32)
         n = C.c_int()
         _check(self.lib.sph_slab_column_counts(self._ctx, out.ctypes.data, out.size, C.byref(n)))
-        return out
+        return out[:n.value]  # the columns of the last sort (fewer than now if the slab has been widened since)
 
     # -- state ------------------------------------------------------------------------------------
     @property
@@ -297,11 +300,10 @@ class SlabSimulation:
 
     def load_info(self):
         """(particles per own column at the last sort, max column shift): one device round trip."""
-        lo, hi, _ = self.columns()
-        out = np.empty(hi - lo, np.int32)
+        out = np.empty(self.columns()[2], np.int32)
         n, v = C.c_int(), C.c_float()
         _check(self.lib.sph_slab_load_info(self._ctx, out.ctypes.data, out.size, C.byref(n), C.byref(v)))
-        return out, float(v.value)
+        return out[:n.value], float(v.value)
 
     def max_column_shift(self):
         """Columns a particle can cross in the next step: max |vx| * dt / cell over this slab's particles."""
@@ -321,6 +323,8 @@ class SlabSimulation:
         if records is None or records.shape[0] == 0:
             return
         assert records.is_cuda and records.dtype == self.torch.float32 and records.is_contiguous()
+        # torch (or RCCL through it) filled `records` on torch's current stream; the context reads them on its own
+        _check(self.lib.sph_stream_wait(self._ctx, C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
         _check(self.lib.sph_slab_append(self._ctx, records.data_ptr(), int(records.shape[0])))
 
     def step(self, nsteps=1):

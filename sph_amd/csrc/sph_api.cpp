@@ -63,6 +63,9 @@ struct sph_context {
   int gn = 0, col_lo = 0, col_hi = 0, cols_capacity = 0;
   int n_last_own = 0;                 // particles integrated by the last step (debug downloads)
   int dbg_stride = 0;                 // plane stride of dbg.force = particle count the last step was launched with
+  DevParams sorted_dev{};             // grid (nx, own_lo, ...) of the last sort: what the start table and the intermediates
+  int sorted_col_lo = 0, sorted_col_hi = 0;  // of that step are indexed by, whatever set_columns/set_params did since
+  hipEvent_t wait_event = nullptr;    // sph_stream_wait
   int32_t* d_counters = nullptr;      // [0],[1] pack counters  [2] own count  [3] trash count after a step
                                       // [4] stray received records (cumulative)  [5] max column shift (float bits)
   int32_t* h_counters = nullptr;      // pinned mirror
@@ -318,6 +321,9 @@ int one_step(sph_context* c) {
                  c->slab ? c->d_counters + 2 : nullptr, c->nmask, mode); }
   HIP_TRY(hipGetLastError());
   c->dbg_stride = n;
+  c->sorted_dev = c->dev;
+  c->sorted_col_lo = c->col_lo;
+  c->sorted_col_hi = c->col_hi;
   if (c->slab) {
     // ghosts and emigrants drop out here: only own-column particles were written back
     c->pre_valid = false;
@@ -329,6 +335,7 @@ int one_step(sph_context* c) {
                        c->pre_rec[0], c->pre_rec[1], c->pre_cap, c->d_counters);
       c->pre_valid = true;
     }
+    if (n == 0) HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));  // no kernel ran to write them
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     c->n_pending = true;
   } else {
@@ -446,6 +453,7 @@ int sph_destroy(sph_context* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
+  if (c->wait_event) (void)hipEventDestroy(c->wait_event);
   free_state(&c->cur);
   (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.rec); (void)hipFree(c->sorted.id);
   (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand); (void)hipFree(c->nmask.nnb);
@@ -712,7 +720,7 @@ int sph_slab_download_debug(sph_context* c, float* rho, float* force, int32_t* n
   int32_t* d_ncount = (int32_t*)(d_force + 3 * n);
   int32_t* d_cell = d_ncount + n;
   // the force plane stride is the launch size of the step that wrote it: recover it from the step's n
-  launch_join_debug(c->stream, c->dev, c->grid.start, (int)n, c->dbg_stride, c->sorted.rec, c->dbg.force, c->dbg.ncount,
+  launch_join_debug(c->stream, c->sorted_dev, c->grid.start, (int)n, c->dbg_stride, c->sorted.rec, c->dbg.force, c->dbg.ncount,
                     c->grid.cell_s, rho ? d_rho : nullptr, force ? d_force : nullptr, ncount ? d_ncount : nullptr,
                     cell ? d_cell : nullptr);
   HIP_TRY(hipGetLastError());
@@ -814,7 +822,9 @@ static int load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, 
   if (!c || !counts) return fail(SPH_ERR_INVALID, "NULL argument");
   if (!c->stepped) return fail(SPH_ERR_STATE, "column counts come from the last step's sort: step first");
   HIP_TRY(hipSetDevice(c->device));
-  const int own = c->col_hi - c->col_lo;
+  // the start table belongs to the grid of the last sort, not to what set_columns/set_params may have set since
+  const DevParams& G = c->sorted_dev;
+  const int own = c->sorted_col_hi - c->sorted_col_lo;
   if (ncols) *ncols = own;
   if (own > capacity) return fail(SPH_ERR_CAPACITY, "%d own columns do not fit the caller's capacity %d", own, capacity);
   if (max_shift) {
@@ -824,9 +834,9 @@ static int load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, 
     launch_max_column_shift(c->stream, c->dev, c->cur, c->n, c->d_counters + 5);
     HIP_TRY(hipMemcpyAsync(c->h_counters + 5, c->d_counters + 5, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   }
-  launch_column_counts(c->stream, c->grid.start, c->dev.nx, c->dev.ny * c->dev.nz, c->d_colcounts);
+  launch_column_counts(c->stream, c->grid.start, G.nx, G.ny * G.nz, c->d_colcounts);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(counts, c->d_colcounts + c->dev.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost,
+  HIP_TRY(hipMemcpyAsync(counts, c->d_colcounts + G.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (max_shift) memcpy(max_shift, c->h_counters + 5, sizeof(float));
@@ -872,6 +882,16 @@ int sph_slab_max_column_shift(sph_context* c, float* columns) {
 int sph_get_stream(sph_context* c, void** stream) {
   if (!c || !stream) return fail(SPH_ERR_INVALID, "NULL argument");
   *stream = (void*)c->stream;
+  return SPH_OK;
+}
+
+int sph_stream_wait(sph_context* c, void* producer_stream) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if ((hipStream_t)producer_stream == c->stream) return SPH_OK;  // same stream: already ordered
+  if (!c->wait_event) HIP_TRY(hipEventCreateWithFlags(&c->wait_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->wait_event, (hipStream_t)producer_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->wait_event, 0));
   return SPH_OK;
 }
 

@@ -122,8 +122,7 @@ int main(int argc, char** argv) {
     dam_break_block(side, seed, &p, &pos, &vel);
   } else {
     // the reference's own scene, through the drop-in initParticles (main.cpp:27)
-    std::string env = "SPH_AMD_SEED=" + std::to_string(seed);
-    putenv(const_cast<char*>(env.c_str()));
+    setenv("SPH_AMD_SEED", std::to_string(seed).c_str(), 1);  // copies, unlike putenv
     float *pp = nullptr, *vv = nullptr;
     initParticles(&pp, &vv, n);
     pos.assign(pp, pp + (size_t)n * 3);

@@ -260,3 +260,42 @@ def test_record_capacity_error():
         b.pack()
     assert e.value.code == 4  # SPH_ERR_CAPACITY, reported instead of overrunning the buffer
     b.close()
+
+
+def test_empty_reupload_after_a_step_stays_empty(oracle):
+    """A slab that held particles, is re-uploaded empty and stepped must report zero particles afterwards (the
+    count of the earlier step must not come back)."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=10)
+    gn = capi.global_cells(p)
+    b = capi.SlabSimulation(p, n_max=ids.size, col_lo=0, col_hi=gn)
+    b.upload(pos, vel, ids)
+    b.step(1)
+    assert b.n == ids.size
+    b.upload(pos[:0], vel[:0], ids[:0])
+    b.step(1)
+    assert b.n == 0
+    gp, gv, gi = b.download()
+    assert gp.shape[0] == 0
+    b.close()
+
+
+def test_column_counts_describe_the_last_sort_after_the_cuts_moved(oracle):
+    """Column counts asked for between sph_slab_set_columns and the next step are those of the columns the last step
+    sorted, not a misindexed read through the new cuts."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=12)
+    gn = capi.global_cells(p)
+    cols = oracle.cell_ids(p, pos) // (gn * gn)
+    lo, hi = int(cols.min()), int(cols.max()) + 1
+    mid = (lo + hi) // 2
+    b = capi.SlabSimulation(p, n_max=ids.size, col_lo=0, col_hi=mid, cols_capacity=gn)
+    m = cols < mid
+    b.upload(pos[m], vel[m], ids[m])
+    b.step(1)
+    before = b.column_counts().copy()
+    assert before.size == mid and before.sum() == b.n
+    b.set_columns(0, mid + 1)
+    after = b.column_counts()
+    assert np.array_equal(after, before)
+    b.close()
