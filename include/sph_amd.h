@@ -49,9 +49,19 @@ enum {
   /* Keep per-particle total force density and neighbour counts of the last step for
    * sph_download_debug (costs 16 B/particle of extra stores per step). */
   SPH_FLAG_KEEP_DEBUG = 1u << 2,
-  /* Ablation switch for the density and force passes; results are the same bit for bit.
-   * LANE_SWEEP: plain one-lane-per-particle sweep: distance test and pair arithmetic in one loop, no candidate mask. */
-  SPH_FLAG_LANE_SWEEP = 1u << 3
+  /* Ablation switch for the density and force passes: plain one-lane-per-particle sweep, distance test and pair
+   * arithmetic in one loop, no candidate mask, reference arithmetic; same results bit for bit as
+   * SPH_FLAG_REFERENCE_ARITH. */
+  SPH_FLAG_LANE_SWEEP = 1u << 3,
+  /* Evaluate every pair term the way the reference's x86-64 object does: kernel coefficient times polynomial
+   * formed in double and rounded once (compute.cpp:45,56,68,80,92), correctly rounded sqrt and IEEE divisions
+   * (:143,:170,:204,:242,:252), no fused multiply-adds.  With it the default summation order (stencil order) is
+   * reproduced bit for bit by a CPU program that sums in the same order; SPH_FLAG_EXACT_ORDER implies it.
+   * Without it (the default) the same terms are evaluated with fp32 coefficients, hardware reciprocal and
+   * reciprocal square root refined by one Newton step, and fused multiply-adds: each term within a few ulp of
+   * the reference's, about a third of the instructions.  Which pairs interact (the test sqrtf(r2) <= h), cell
+   * ids and neighbour counts are exact in every mode. */
+  SPH_FLAG_REFERENCE_ARITH = 1u << 4
 };
 
 /*
@@ -131,6 +141,10 @@ int sph_upload_device(sph_context* ctx, const float* d_pos_aos, const float* d_v
  */
 int sph_step(sph_context* ctx, int nsteps);
 int sph_sync(sph_context* ctx);
+/* sph_step with a HIP event recorded on the context's stream before every step and behind the last one;
+ * waits for the steps and returns the device time of each in step_ms[nsteps] (milliseconds).  Measurement aid:
+ * the reference has no timers (its main loop, main.cpp:31-35, is not instrumented). */
+int sph_step_profile(sph_context* ctx, int nsteps, float* step_ms);
 
 /* HBM -> host, caller order (via the id permutation).  Either pointer may be NULL. */
 int sph_download(sph_context* ctx, float* pos_aos, float* vel_aos);

@@ -30,6 +30,7 @@ _SIGNATURES = [
     ("sph_upload_device", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int]),
     ("sph_step", C.c_int, [_CTX, C.c_int]),
     ("sph_sync", C.c_int, [_CTX]),
+    ("sph_step_profile", C.c_int, [_CTX, C.c_int, C.c_void_p]),
     ("sph_download", C.c_int, [_CTX, C.c_void_p, C.c_void_p]),
     ("sph_download_device", C.c_int, [_CTX, C.c_void_p, C.c_void_p]),
     ("sph_download_debug", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -176,6 +177,12 @@ class Simulation:
 
     def sync(self):
         _check(self.lib.sph_sync(self._ctx))
+
+    def step_profile(self, nsteps):
+        """nsteps steps, waited for; returns the device time of every step in ms (HIP events on the context's stream)."""
+        ms = np.zeros(int(nsteps), np.float32)
+        _check(self.lib.sph_step_profile(self._ctx, int(nsteps), ms.ctypes.data))
+        return ms
 
     def download(self):
         n = self.n

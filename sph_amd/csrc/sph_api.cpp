@@ -195,6 +195,12 @@ void derive(const sph_params* p, int nx, int cx_off, int gn, DevParams* d) {
   d->cx_off = cx_off;
   d->gnx = gn;
   d->tension = (p->flags & SPH_FLAG_SURFACE_TENSION) ? 1 : 0;
+  d->k_dens = (float)((double)p->mass * d->c_poly6);
+  d->k_press = (float)(-0.5 * (double)p->mass * d->c_spiky_grad);
+  d->k_visc = (float)((double)d->visc_m * d->c_visc_lapl);
+  d->k_tgrad = (float)((double)p->mass * d->c_poly6_grad);
+  d->k_tlapl = (float)((double)p->mass * d->c_poly6_lapl);
+  d->c2rho0 = d->c2 * p->rho0;
 }
 
 // Where a context's device buffers come from: one hipMalloc each (sph_create), or consecutive 256-byte-aligned
@@ -308,12 +314,19 @@ int one_step(sph_context* c) {
   { Timed t(c, CAT_HASH); launch_hash(c->stream, c->dev, c->cur, n, c->grid); }
   { Timed t(c, CAT_SCAN); launch_scan(c->stream, c->grid); }
   { Timed t(c, CAT_REORDER); launch_reorder(c->stream, c->cur, c->sorted, n, c->grid); }
-  SweepMode mode = SWEEP_MASKED;
+  SweepMode mode = SWEEP_FAST;
   if (exact) mode = SWEEP_EXACT;
   else if (c->params.flags & SPH_FLAG_LANE_SWEEP) mode = SWEEP_PLAIN;
-  if (mode == SWEEP_MASKED) { Timed t(c, CAT_SEARCH); launch_neighbours(c->stream, c->dev, c->sorted, n, c->grid, c->nmask); }
-  { Timed t(c, CAT_DENSITY);
-    launch_density(c->stream, c->dev, c->sorted, n, c->grid, keep ? c->dbg.ncount : nullptr, c->nmask, mode); }
+  else if (c->params.flags & SPH_FLAG_REFERENCE_ARITH) mode = SWEEP_MASKED;
+  if (mode == SWEEP_MASKED || mode == SWEEP_FAST) {  // fast arithmetic: the search computes the density on the way
+    Timed t(c, CAT_SEARCH);
+    launch_neighbours(c->stream, c->dev, c->sorted, n, c->grid, c->nmask, mode == SWEEP_FAST,
+                      keep ? c->dbg.ncount : nullptr);
+  }
+  if (mode != SWEEP_FAST) {
+    Timed t(c, CAT_DENSITY);
+    launch_density(c->stream, c->dev, c->sorted, n, c->grid, keep ? c->dbg.ncount : nullptr, c->nmask, mode);
+  }
   State out = c->cur;
   if (!c->slab) out.id = nullptr;  // same particles, same order: the id array is swapped below instead
   { Timed t(c, CAT_FORCE);
@@ -521,6 +534,28 @@ int sph_step(sph_context* c, int nsteps) {
     if (rc) return rc;
   }
   return SPH_OK;
+}
+
+int sph_step_profile(sph_context* c, int nsteps, float* step_ms) {
+  if (!c || !step_ms) return fail(SPH_ERR_INVALID, "NULL argument");
+  if (nsteps < 0) return fail(SPH_ERR_INVALID, "nsteps < 0");
+  if (!c->uploaded) return fail(SPH_ERR_STATE, "sph_step_profile before sph_upload");
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<hipEvent_t> ev((size_t)nsteps + 1, nullptr);
+  int rc = SPH_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) rc = fail(SPH_ERR_HIP, "hipEventCreate failed");
+  for (int s = 0; s < nsteps && rc == SPH_OK; s++) {
+    if (hipEventRecord(ev[s], c->stream) != hipSuccess) rc = fail(SPH_ERR_HIP, "hipEventRecord failed");
+    if (rc == SPH_OK) rc = one_step(c);
+  }
+  if (rc == SPH_OK && hipEventRecord(ev[nsteps], c->stream) != hipSuccess) rc = fail(SPH_ERR_HIP, "hipEventRecord failed");
+  if (rc == SPH_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPH_ERR_HIP, "stream sync failed");
+  for (int s = 0; s < nsteps && rc == SPH_OK; s++)
+    if (hipEventElapsedTime(&step_ms[s], ev[s], ev[s + 1]) != hipSuccess) rc = fail(SPH_ERR_HIP, "hipEventElapsedTime failed");
+  for (auto e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
 }
 
 int sph_sync(sph_context* c) {

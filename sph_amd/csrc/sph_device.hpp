@@ -17,6 +17,12 @@ __device__ inline int cell_coord(float x, float cell, int gn) {
 }
 
 __device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
+__device__ inline float dist2_to(const float4& a, const float4& b, float& dx, float& dy, float& dz) {
+  dx = a.x - b.x;  // :140-142
+  dy = a.y - b.y;
+  dz = a.z - b.z;
+  return dist2(dx, dy, dz);
+}
 
 // Correctly rounded fp32 square root (what sqrtf gives on the reference's host), for the r of :143.
 // hipcc expands sqrtf into v_sqrt_f32 (1 ulp) plus a correction: the candidates one ulp below and above are
@@ -123,6 +129,53 @@ __device__ inline PairOut pair_eval(const DevParams& P, float dx, float dy, floa
     o.v[6] = o.v[7] = o.v[8] = o.v[9] = 0.0f;
   }
   return o;
+}
+
+// ---- the same contribution in fast arithmetic ------------------------------------------------------------------
+// Same terms as pair_eval, evaluated the cheap way: fp32 coefficients folded with the mass factors on the host,
+// 1/r from v_rsq_f32 with one Newton step, 1/rho_j precomputed per particle by the density pass, fused multiply-adds.
+// Differs from the reference's value of each term by a few ulp (the reference itself is a few ulp from the exact
+// value: sqrt, up to three divisions and a double product, each rounded), never in which pairs contribute: that is
+// decided by the neighbour mask, which is exact.  Uses r2 where the reference re-squares its rounded r.
+//   pressure   -m (p_i + p_j) / (2 rho_j) * c_spiky (h - r)^2 * d/r                         (:56,:170-178)
+//   viscosity  (v_j - v_i) * mu m c_visc (h - r) / rho_j                                    (:45,:204-208)
+//   colour     grad: m c_grad r (h2 - r2)^2 / rho_j * d/r = m c_grad (h2 - r2)^2 / rho_j * d      (:80,:242-250)
+//              lapl: m c_lapl (4 r2 (h2 - r2) - (h2 - r2)^2) / rho_j                        (:92,:252)
+__device__ inline float fast_rsqrt(float x) {  // 1/sqrt(x), x > 0
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float e = __builtin_fmaf(-x * y, y, 1.0f);  // 1 - x y^2
+  return __builtin_fmaf(0.5f * y, e, y);
+}
+__device__ inline float fast_rcp(float x) {
+  const float y = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, y, 1.0f);
+  return __builtin_fmaf(e, y, y);
+}
+__device__ inline void pair_accumulate_fast(const DevParams& P, float* a, float dx, float dy, float dz, float pi,
+                                            float rho_j, float inv_rho_j, float dvx, float dvy, float dvz) {
+  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  const float rinv = r2 > 0.0f ? fast_rsqrt(r2) : 0.0f;  // coincident particles: no direction (vecNormalize of 0, :36-37)
+  const float r = r2 * rinv;
+  const float hr = P.h - r;
+  const float pj = __builtin_fmaf(P.c2, rho_j, -P.c2rho0);  // :164
+  const float sp = (P.k_press * (hr * hr)) * ((pi + pj) * inv_rho_j) * rinv;
+  a[0] = __builtin_fmaf(sp, dx, a[0]);
+  a[1] = __builtin_fmaf(sp, dy, a[1]);
+  a[2] = __builtin_fmaf(sp, dz, a[2]);
+  const float tv = (P.k_visc * hr) * inv_rho_j;
+  a[3] = __builtin_fmaf(dvx, tv, a[3]);
+  a[4] = __builtin_fmaf(dvy, tv, a[4]);
+  a[5] = __builtin_fmaf(dvz, tv, a[5]);
+  if (P.tension) {
+    const float d = P.h2 - r2;
+    const float d2 = d * d;
+    const float mg = (P.k_tgrad * d2) * inv_rho_j;
+    a[6] = __builtin_fmaf(mg, dx, a[6]);
+    a[7] = __builtin_fmaf(mg, dy, a[7]);
+    a[8] = __builtin_fmaf(mg, dz, a[8]);
+    const float poly = __builtin_fmaf(4.0f * r2, d, -d2);
+    a[9] = __builtin_fmaf(P.k_tlapl * poly, inv_rho_j, a[9]);
+  }
 }
 
 // ---- per-particle epilogue: total force, symplectic Euler, tank walls --------------------------------

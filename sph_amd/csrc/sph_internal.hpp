@@ -25,6 +25,14 @@ struct DevParams {
   int dens_lo, dens_hi;      // local x-columns whose density is needed: own plus one ghost column per side
   int tension;               // surface-tension term on/off
   int xcd_run;               // consecutive workgroups of a sweep that share an XCD (set by the sweep launchers)
+  // fp32 products of mass/viscosity and the kernel coefficients, for the fast-arithmetic sweeps (rounded once on
+  // the host from the double coefficients above)
+  float k_dens;              // m * c_poly6                      density, compute.cpp:68,146
+  float k_press;             // -m/2 * c_spiky_grad              pressure, :56,:170
+  float k_visc;              // dynVisc * m * c_visc_lapl        viscosity, :45,:204
+  float k_tgrad;             // m * c_poly6_grad                 colour gradient, :80,:242
+  float k_tlapl;             // m * c_poly6_lapl                 colour laplacian, :92,:252
+  float c2rho0;              // c2 * rho0
 };
 
 // Structure-of-arrays particle state in HBM.
@@ -38,7 +46,7 @@ struct State {
 // `rec` holds position and velocity + density side by side, so one 128-byte line serves both loads (with two
 // separate arrays the pass fetched twice as many lines into L1, which bounds it where the fluid is compressed).
 struct ParticleRec {
-  float4 pos;  // x, y, z, unused
+  float4 pos;  // x, y, z, 1/density (w is written by the fast-arithmetic density pass only)
   float4 vel;  // vx, vy, vz, density (w is written by the density pass)
 };
 // The neighbour search reads up to kSearchOverread slots past the end of a stencil run (and masks them off), so
@@ -83,15 +91,19 @@ struct DebugBuffers {
 
 constexpr int kScanItems = 4096;  // cells per scan block
 
-// Flavour of the density/force sweeps: masked is the default; the others exist for verification and ablation.
-enum SweepMode { SWEEP_MASKED = 0, SWEEP_PLAIN = 1, SWEEP_EXACT = 2 };
+// Flavour of the density/force sweeps.  All but SWEEP_PLAIN walk the neighbour bitmask written by the search kernel.
+// SWEEP_FAST is the default: fp32 coefficients and hardware reciprocals in the pair arithmetic.  The other three
+// evaluate every term with the reference's arithmetic (double coefficient products, IEEE division and square root):
+// MASKED in stencil order (bit-identical to the CPU grid twin), PLAIN the same without the mask (ablation), EXACT in
+// ascending particle id (bit-identical to the reference).
+enum SweepMode { SWEEP_MASKED = 0, SWEEP_PLAIN = 1, SWEEP_EXACT = 2, SWEEP_FAST = 3 };
 
 void launch_split_aos(hipStream_t s, const float* pos_aos, const float* vel_aos, int n, State st);
 void launch_hash(hipStream_t s, const DevParams& P, const State& in, int n, GridBuffers g);
 void launch_scan(hipStream_t s, GridBuffers g);
 void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g);
 void launch_neighbours(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
-                       const NeighbourMask& nm);
+                       const NeighbourMask& nm, bool with_density, int32_t* ncount);
 void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
                     int32_t* ncount, const NeighbourMask& nm, SweepMode mode);
 void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,

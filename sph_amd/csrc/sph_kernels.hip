@@ -247,7 +247,7 @@ __global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict
   int d = b + r;
   const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
   out.pos[d] = pos;
-  out.rec[d].pos = pos;
+  out.rec[d].pos = pos;  // w receives 1/density (fast-arithmetic density pass)
   out.rec[d].vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
   out.id[d] = my;
   cell_s[d] = c;

@@ -119,13 +119,6 @@ __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ 
   return trips;
 }
 
-__device__ inline float dist2_to(const float4& a, const float4& b, float& dx, float& dy, float& dz) {
-  dx = a.x - b.x;  // :140-142
-  dy = a.y - b.y;
-  dz = a.z - b.z;
-  return dist2(dx, dy, dz);
-}
-
 // Slot range [lo, hi) of the local x-columns [col_lo, col_hi).
 __device__ inline void column_slots(const DevParams& P, const int32_t* __restrict__ start, int col_lo, int col_hi,
                                     int& lo, int& hi) {
@@ -139,8 +132,13 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 // trip (four independent 16-byte gathers in flight) and packs the outcomes into the particle's mask:
 // bit q <=> the q-th candidate passes sqrtf(r2) <= h, tested as r2 <= r2_max with
 // r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
+// WITH_DENSITY (fast arithmetic): the density is accumulated on the spot, rho_i = (m c_poly6)_fp32 * sum over the
+// neighbours of (h2 - r2)^3 (:65-68,:146 with r2 in place of the re-squared rounded r; no square root, no double
+// product), and written with its refined reciprocal into the particle's record: no separate density pass.
+template <bool WITH_DENSITY>
 __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
-                                                       const int32_t* __restrict__ cell_s, NeighbourMask nm) {
+                                                       const int32_t* __restrict__ cell_s, NeighbourMask nm,
+                                                       int32_t* __restrict__ ncount) {
   __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
@@ -150,6 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   const int trips = fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
   unsigned word = 0;
   int q = 0, cnt = 0;  // q: candidates seen so far = index of the next one in the flattened stencil
+  float sum = 0.0f;
   float dx, dy, dz;
   // the number of trips is known up front, so the loop needs no end-of-stencil test: a trip always finds a run
   int k = -1, shift = 0, qe = 0;  // current run, its slot shift, its end in q
@@ -170,7 +169,12 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
 #pragma unroll
     for (int u = 0; u < kAhead; u++) {
       const float r2 = dist2_to(pi, cand[u], dx, dy, dz);
-      bits |= (r2 <= P.r2_max ? 1u : 0u) << u;
+      const bool hit = WITH_DENSITY ? (r2 <= P.r2_max && u < m) : r2 <= P.r2_max;
+      bits |= (hit ? 1u : 0u) << u;
+      if (WITH_DENSITY) {
+        const float d = hit ? P.h2 - r2 : 0.0f;
+        sum = __builtin_fmaf(d * d, d, sum);
+      }
     }
     bits &= (1u << m) - 1u;
     cnt += __popc(bits);
@@ -185,6 +189,12 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   if ((q & 31) != 0 && (q >> 5) < kMaskWords) nm.words[(size_t)(q >> 5) * nm.stride + s] = word;
   nm.ncand[s] = q;
   nm.nnb[s] = cnt;
+  if (WITH_DENSITY) {
+    const float rho = P.k_dens * sum;
+    st.rec[s].vel.w = rho;
+    st.rec[s].pos.w = fast_rcp(rho);
+    if (ncount) ncount[s] = cnt;
+  }
 }
 
 // Lanes of a wave run in lockstep, so a wave takes as long as its particle with the most neighbours.  The force
@@ -294,7 +304,10 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
       q = rt.qend[k][col];
       for (int j = b; j < e; j++) {
         const float4 pj = st.pos[j];
-        if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) visit(pj, WITH_VEL ? st.rec[j].vel : pj);
+        if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) {
+          if (WITH_VEL) visit(st.rec[j].pos, st.rec[j].vel);  // the record's w components carry 1/density and density
+          else visit(pj, pj);
+        }
       }
     }
   }
@@ -302,7 +315,9 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
 
 // ---- density ----------------------------------------------------------------------------------------------------
 // rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (:131-150).  Written to rec[s].vel.w.
-template <int MODE>
+// FAST (masked flavour only): rho_i = (m c_poly6)_fp32 * sum (h2 - r2)^3 - no square root, no double product, r2 in
+// place of the re-squared rounded r - and 1/rho_i, refined, stored beside it for the force pass.
+template <int MODE, bool FAST>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
@@ -321,7 +336,12 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   int cnt = 0;
   float dx, dy, dz;
   auto add = [&](float r2) {
-    acc += P.m * w_poly6(P, sqrt_rn(r2));  // :144-146
+    if (FAST) {
+      const float d = P.h2 - r2;
+      acc = __builtin_fmaf(d * d, d, acc);
+    } else {
+      acc += P.m * w_poly6(P, sqrt_rn(r2));  // :144-146
+    }
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
@@ -356,12 +376,16 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
       last = best;
     }
   }
+  if (FAST) {
+    acc *= P.k_dens;
+    st.rec[s].pos.w = fast_rcp(acc);
+  }
   st.rec[s].vel.w = acc;
   if (ncount) ncount[s] = cnt;
 }
 
 // ---- forces, integration, walls -------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool FAST>
 __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State out, int n,
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
@@ -396,9 +420,13 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
 
   auto add_pair = [&](const float4& pj, const float4& vj) {
     const float r2 = dist2_to(pi4, pj, dx, dy, dz);
-    const PairOut w = pair_eval(P, dx, dy, dz, r2, pi, vj.w, vj.x - vi4.x, vj.y - vi4.y, vj.z - vi4.z);
+    if (FAST) {
+      pair_accumulate_fast(P, a, dx, dy, dz, pi, vj.w, pj.w, vj.x - vi4.x, vj.y - vi4.y, vj.z - vi4.z);
+    } else {
+      const PairOut w = pair_eval(P, dx, dy, dz, r2, pi, vj.w, vj.x - vi4.x, vj.y - vi4.y, vj.z - vi4.z);
 #pragma unroll
-    for (int q = 0; q < kForceComps; q++) a[q] += w.v[q];
+      for (int q = 0; q < kForceComps; q++) a[q] += w.v[q];
+    }
   };
 
   if (MODE == SWEEP_MASKED) {
@@ -457,10 +485,13 @@ static DevParams with_xcd_run(const DevParams& P0, int n) {
 }
 
 void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
-                       const NeighbourMask& nm) {
+                       const NeighbourMask& nm, bool with_density, int32_t* ncount) {
   if (n <= 0) return;
   const DevParams P = with_xcd_run(P0, n);
-  hipLaunchKernelGGL(k_neighbours, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm);
+  if (with_density)
+    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount);
+  else
+    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount);
 }
 
 void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
@@ -469,11 +500,13 @@ void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n,
   const DevParams P = with_xcd_run(P0, n);
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL(k_density<SWEEP_EXACT>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
   else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL(k_density<SWEEP_PLAIN>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+  else if (mode == SWEEP_FAST)
+    hipLaunchKernelGGL((k_density<SWEEP_MASKED, true>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
   else
-    hipLaunchKernelGGL(k_density<SWEEP_MASKED>, grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_MASKED, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
 }
 
 void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const State& out, int n,
@@ -483,11 +516,13 @@ void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const St
   const DevParams P = with_xcd_run(P0, n);
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL(k_force<SWEEP_EXACT>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
   else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL(k_force<SWEEP_PLAIN>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+  else if (mode == SWEEP_FAST)
+    hipLaunchKernelGGL((k_force<SWEEP_MASKED, true>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
   else
-    hipLaunchKernelGGL(k_force<SWEEP_MASKED>, grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_MASKED, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
 }
 
 }  // namespace sph

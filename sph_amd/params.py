@@ -9,6 +9,7 @@ SPH_FLAG_SURFACE_TENSION = 1 << 0
 SPH_FLAG_EXACT_ORDER = 1 << 1
 SPH_FLAG_KEEP_DEBUG = 1 << 2
 SPH_FLAG_LANE_SWEEP = 1 << 3
+SPH_FLAG_REFERENCE_ARITH = 1 << 4
 
 
 class SphParams(C.Structure):
