@@ -9,10 +9,17 @@ N = 1 : the 1M-particle dam-break block (100^3 jittered lattice in the corner of
 N > 1 : launched by torch.distributed.run, one rank per GPU; the dam-break block grows along x
         with N (weak scaling: per-GPU particle count fixed) and is slab-decomposed along x.
 
+The dam break is not a steady state: a step costs 0.25 ms while the block is still at rest density
+(13 neighbours per particle) and more than twice that at peak compression (53 neighbours).  So
+that one number means one thing whatever --steps/--warmup are, the timed window always starts at
+the same PHASE: an untimed pre-roll of --preroll steps (default 60: peak compression of the
+collapse, the most expensive phase), then W warm-up steps, then K timed steps.  The rest-density
+figure (steps 5-25 from the initial block) is printed as a labelled extra.
+
 Prints ONE JSON line on rank 0 with the metric (particle-updates/s, whole job), a roofline
 object for the dominant kernel (HIP-event durations measured inside the timed region on the
 library's own stream) and a cpu_baseline object (the reference algorithm timed on this box's
-host cores on a bounded sample).
+host cores on bounded samples).
 """
 import argparse
 import json
@@ -29,15 +36,13 @@ from sph_amd import capi, scenes  # noqa: E402
 from sph_amd.params import SPH_FLAG_SURFACE_TENSION  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
-VALU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock
 
 # Algorithmic HBM bytes per particle and kernel: every array touched once per pass, neighbour
 # re-reads assumed served on-chip.
 BYTES_PER_PARTICLE = {
     "hash": 16,      # R pos 12, W cell 4
     "reorder": 56,   # R key 4 (histogram) ; R key 4 + R pos,vel 24 + W pos,vel 24 (scatter)
-    "search": 12,    # R pos 12 (+ candidate bitmask W, 4 B per 32 candidates)
-    "density": 16,   # R pos 12, W rho 4
+    "search": 16,    # search + density in one kernel: R pos 12, W rho 4 (+ candidate bitmask W, 4 B per 32 candidates)
     "force": 52,     # R pos 12, vel 12, rho 4 ; W pos 12, vel 12
 }
 
@@ -45,61 +50,79 @@ BYTES_PER_PARTICLE = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preroll", type=int, default=60,
+                    help="untimed steps before the warm-up: the phase of the collapse the timed window starts in")
     ap.add_argument("--side", type=int, default=100, help="dam-break block is side^3 particles per GPU")
-    ap.add_argument("--workload", default="dam_break", choices=["dam_break", "uniform_cube"])
+    ap.add_argument("--workload", default="dam_break", choices=["dam_break", "uniform_cube", "sloshing"])
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rest-figure", action="store_true", help="skip the rest-density extra (steps 5-25)")
     ap.add_argument("--rebalance-every", type=int, default=2, help="multi-GPU: steps between cut-plane moves")
-    ap.add_argument("--cpu-sample-side", type=int, default=28,
-                    help="CPU baseline runs the all-pairs reference algorithm on a side^3 sub-block")
+    ap.add_argument("--transport", default="library", choices=["library", "torch"],
+                    help="multi-GPU: halo exchange issued by the library (RCCL from C++) or by torch.distributed")
     return ap.parse_args()
 
 
+CPU_SAMPLE_SIDES = (14, 27, 37)  # 2 744, 19 683 and 50 653 particles: the sizes the all-pairs fit is made on
+
+
 def cpu_baseline(args):
-    """The reference algorithm (all-pairs) on host cores, on a bounded sample of the workload."""
+    """The reference algorithm (all-pairs, O(N^2)) on host cores, on bounded samples of the workload: side^3
+    sub-blocks of the dam-break field at three sizes, a t = c*N^2 fit through them, and its value at the
+    benchmark's particle count."""
     from oracle import Oracle, Ref  # checker only: timed here as the reported CPU baseline
-    side = args.cpu_sample_side
-    pos, vel, p = scenes.dam_break(side)
-    n = pos.shape[0]
     orc = Oracle()
     threads = orc.num_threads()
-    if Ref.available():
-        ref = Ref(p)
-        kind = "reference"
+    kind = "reference" if Ref.available() else "port"
+    points = []
+    for side in CPU_SAMPLE_SIDES:
+        pos, vel, p = scenes.dam_break(side)
+        n = pos.shape[0]
+        if kind == "reference":
+            ref = Ref(p)
 
-        def step():
-            ref.step(pos, vel)
-    else:
-        kind = "port"
-
-        def step():
-            orc.step_allpairs(p, pos, vel)
-    step()  # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        step()
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 20:
-            break
-    per_step = dt / reps
+            def step():
+                ref.step(pos, vel)
+        else:
+            def step():
+                orc.step_allpairs(p, pos, vel)
+        step()  # warm-up (thread pool, page faults)
+        budget = 1.0 if side == CPU_SAMPLE_SIDES[0] else 6.0
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            step()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= 50:
+                break
+        points.append((n, dt / reps, reps))
+    ns = np.array([q[0] for q in points], np.float64)
+    ts = np.array([q[1] for q in points], np.float64)
+    slope = float(np.polyfit(np.log(ns[1:]), np.log(ts[1:]), 1)[0])  # measured exponent between the two large sizes
+    c = float((ts * ns ** 2).sum() / (ns ** 4).sum())               # least-squares t = c N^2
+    n_bench = args.side ** 3
+    t_bench = c * float(n_bench) ** 2
     return {
-        "value": n / per_step,
+        "value": n_bench / t_bench,
         "unit": "particle-updates/s",
         "cores": threads,
         "kind": kind,
-        "sample": (f"{reps} all-pairs steps of a {side}^3 = {n}-particle sub-block of the dam-break field "
-                   f"({per_step:.3f} s/step; the algorithm is O(N^2): extrapolated "
-                   f"{per_step * (1e6 / n) ** 2 / 3600.0:.2f} h/step at 1M particles)"),
+        "sample": ("all-pairs steps of side^3 sub-blocks of the dam-break field: " +
+                   ", ".join(f"N={n}: {t:.4f} s/step ({r} steps)" for n, t, r in points) +
+                   f"; fit t = {c:.3e}*N^2 s (measured exponent between the two largest: {slope:.2f}); value = the fit "
+                   f"at N={n_bench}: {t_bench / 3600.0:.2f} h/step"),
+        "points": [{"particles": int(n), "s_per_step": t, "particle_updates_per_s": n / t} for n, t, _ in points],
+        "fit_c_seconds_per_particle_squared": c,
+        "fit_exponent_measured": slope,
     }
 
 
 def cpu_grid_twin(args):
-    """This repository's uniform-grid CPU twin (NOT the reference algorithm: same arithmetic and results, but
-    O(N) neighbour search) on the full workload, for a CPU figure at the size the GPU number is quoted on."""
+    """This repository's uniform-grid CPU twin (NOT the reference algorithm: same terms, but O(N) neighbour
+    search) on the full workload, for a CPU figure at the size the GPU number is quoted on."""
     from oracle import Oracle  # checker only: timed here as a reported CPU figure
     pos, vel, p = scenes.dam_break(args.side)
     orc = Oracle()
@@ -112,51 +135,82 @@ def cpu_grid_twin(args):
     per_step = (time.perf_counter() - t0) / reps
     return {"value": pos.shape[0] / per_step, "unit": "particle-updates/s", "cores": orc.num_threads(),
             "kind": "port, uniform-grid search (not the reference's all-pairs algorithm)",
-            "sample": f"{reps} steps of the full {pos.shape[0]}-particle dam break ({per_step:.3f} s/step)"}
+            "sample": f"{reps} steps of the full {pos.shape[0]}-particle dam break from rest ({per_step:.3f} s/step)"}
 
 
-def from_profile(workload_name, key):
-    """A per-launch figure of the dominant kernel from the committed rocprofv3 --pmc summary of this workload."""
+def profile_figures(workload_name, args):
+    """Counter-derived per-launch figures of the committed rocprofv3 --pmc profile, if and only if that profile was
+    taken over this very window (same workload, pre-roll, warm-up and step count)."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("workload") == workload_name:
-            return t.get(key)
     except (OSError, ValueError):
-        pass
+        return None
+    w = t.get("window", {})
+    if (t.get("workload") == workload_name and w.get("preroll") == args.preroll and w.get("warmup") == args.warmup
+            and w.get("steps") == args.steps):
+        return t
     return None
 
 
 def run_single(args):
     import torch
-    if args.workload == "dam_break":
-        pos, vel, p = scenes.dam_break(args.side)
-        workload = f"dam_break_{args.side}^3"
-    else:
+    if args.workload == "uniform_cube":
         pos, vel, p = scenes.uniform_cube(args.side)
         workload = f"uniform_cube_{args.side}^3"
+    else:
+        pos, vel, p = scenes.dam_break(args.side)
+        workload = f"{args.workload}_{args.side}^3"
     p.flags = SPH_FLAG_SURFACE_TENSION
     n = pos.shape[0]
     dev = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(dev)
     sim = capi.Simulation(p, n_max=n, device=dev)
-    sim.upload(pos, vel)          # inputs resident in HBM before the timed region
-    sim.step(args.warmup)
+    sim.upload(pos, vel)          # inputs resident in HBM before any timed region
+    step0 = [0]
+
+    def advance(k):
+        """k steps; the sloshing workload turns gravity every step (the reference's mutable a_gravity, compute.cpp:12)."""
+        if args.workload == "sloshing":
+            for _ in range(k):
+                sim.set_gravity(scenes.sloshing_gravity(step0[0]))
+                sim.step(1)
+                step0[0] += 1
+        else:
+            sim.step(k)
+            step0[0] += k
+
+    rest = None
+    done = 0
+    if not args.no_rest_figure and args.preroll >= 25 and args.workload != "sloshing":
+        advance(5)
+        sim.sync()
+        ms = sim.step_profile(20)
+        done = 25
+        step0[0] += 20
+        rest = {"window_steps": [5, 25], "ms_per_step": float(ms.mean()), "value": n / (float(ms.mean()) * 1e-3),
+                "note": "block still at rest density (~13 neighbours per particle): the cheapest phase of the workload"}
+    advance(max(0, args.preroll - done))
+    advance(args.warmup)
     sim.sync()
     sim.enable_timing(not args.no_events)
     sim.reset_timings()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sim.step(args.steps)
-    sim.sync()
+    if args.workload == "sloshing":
+        advance(args.steps)
+        sim.sync()
+        step_ms = None
+    else:
+        step_ms = sim.step_profile(args.steps)  # returns when the steps have completed
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = sim.timings()
     gp, _ = sim.download()
     assert np.isfinite(gp).all(), "non-finite positions after the timed region"
     sim.close()
-    return dict(n=n, dt=dt, timings=tm, workload=workload, params=p)
+    return dict(n=n, dt=dt, timings=tm, workload=workload, params=p, step_ms=step_ms, rest=rest)
 
 
 def main():
@@ -171,6 +225,7 @@ def main():
     n, dt, tm = r["n"], r["dt"], r["timings"]
     steps = args.steps
     value = n * steps / dt
+    first = args.preroll + args.warmup
     out = {
         "metric": "particle-updates/sec",
         "value": value,
@@ -185,35 +240,41 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": r["workload"], "particles": n, "tank_size": float(r["params"].tank_size),
-                   "h": float(r["params"].h), "surface_tension": True, "parallelism": "1 GPU"},
+                   "h": float(r["params"].h), "surface_tension": True, "parallelism": "1 GPU",
+                   "arithmetic": "fast (fp32 coefficients, refined rcp/rsq); neighbour sets exact"},
+        "phase": {"preroll_steps": args.preroll, "timed_steps": [first, first + steps],
+                  "description": ("peak compression of the dam-break collapse (~50 neighbours per particle)"
+                                  if args.workload == "dam_break" and 40 <= args.preroll <= 90 else
+                                  f"{args.preroll} steps after the initial state")},
     }
+    if r["step_ms"] is not None and len(r["step_ms"]):
+        sm = r["step_ms"]
+        out["ms_per_step_device"] = {"min": float(sm.min()), "mean": float(sm.mean()), "max": float(sm.max())}
+    if r["rest"]:
+        out["rest_density_extra"] = r["rest"]
     if not args.no_events and tm["steps"] > 0:
         k = tm["steps"]
         per = {name: tm[name + "_ms"] / k for name in ("hash", "scan", "reorder", "search", "density", "force")}
+        prof = profile_figures(r["workload"], args)
         force_s = per["force"] * 1e-3
         achieved = BYTES_PER_PARTICLE["force"] * n / force_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": from_profile(r["workload"], "force_bytes_per_launch"),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("force_bytes_per_launch") if prof else None,
             "bytes_per_particle": BYTES_PER_PARTICLE["force"], "avg_launch_ms": per["force"],
         }
-        df = (BYTES_PER_PARTICLE["density"] + BYTES_PER_PARTICLE["force"]) * n / (
-            (per["search"] + per["density"] + per["force"]) * 1e-3) / 1e9
+        sweeps_ms = per["search"] + per["density"] + per["force"]
+        df = 68.0 * n / (sweeps_ms * 1e-3) / 1e9
         out["roofline_density_force"] = {"bound": "hbm", "achieved": df, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": df / HBM_PEAK_GBS, "bytes_per_particle": 68}
-        # The sweeps are bound by vector-instruction issue, not by HBM: a wave64 instruction holds one of the
-        # chip's 1024 SIMDs for 4 cycles.  Instruction count per launch from the committed counter profile,
-        # duration live.
-        insts = from_profile(r["workload"], "force_valu_wave_insts_per_launch")
-        if insts:
-            peak = 1024 * VALU_CLOCK_HZ / 4.0
-            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_force", "achieved": insts / force_s, "peak": peak,
-                                    "unit": "wave-instructions/s", "frac": insts / force_s / peak,
-                                    "wave_insts_per_launch": insts}
-        step_bytes = sum(BYTES_PER_PARTICLE.values()) - BYTES_PER_PARTICLE["search"]  # the 140 B pipeline model
+                                         "frac": df / HBM_PEAK_GBS, "bytes_per_particle": 68,
+                                         "kernels": "k_neighbours (search + density) + k_force"}
+        step_bytes = 140  # hash 16 + sort 56 + density 16 + force 52: the pipeline model
         whole = step_bytes * n / (dt / steps) / 1e9
         out["roofline_step"] = {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": whole / HBM_PEAK_GBS, "bytes_per_particle": step_bytes}
+        if prof and prof.get("issue_side"):
+            # what actually bounds the gathering sweeps, from counters of this same window (see profiles/)
+            out["issue_side"] = prof["issue_side"]
         out["kernel_ms_per_step"] = per
     if not args.no_cpu_baseline and rank == 0:
         out["cpu_baseline"] = cpu_baseline(args)
