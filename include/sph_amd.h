@@ -248,7 +248,10 @@ int sph_slab_upload(sph_context* ctx, const float* pos_aos, const float* vel_aos
 /* HBM -> host in storage order with ids; *n_out particles (<= capacity). */
 int sph_slab_download(sph_context* ctx, float* pos_aos, float* vel_aos, int32_t* ids,
                       int capacity, int* n_out);
-/* Intermediates of the last step for the particles sph_slab_download returns, same order. */
+/* Number of particles the last step advanced (the context's own particles; what sph_slab_download_debug describes).
+ * sph_num_particles may be larger: it includes records received since for the next step. */
+int sph_slab_last_own(const sph_context* ctx);
+/* Intermediates of the last step for the first sph_slab_last_own particles sph_slab_download returns, same order. */
 int sph_slab_download_debug(sph_context* ctx, float* rho, float* force, int32_t* ncount,
                             int32_t* cell, int capacity);
 
@@ -279,6 +282,40 @@ int sph_slab_lost(sph_context* ctx, int64_t* lost);
  * cross in the next step.  With one exchange per step between direct neighbours, every slab must be
  * at least ceil(that) + 2 columns wide (+ 1 while cut planes move).  Synchronous. */
 int sph_slab_max_column_shift(sph_context* ctx, float* columns);
+
+/* ---- exchange issued by the library, overlapped with the interior columns ----------------------------------------
+ *
+ * Instead of pack / <caller's exchange> / append, a slab context attached to a transport moves its records itself:
+ *   RCCL   ncclSend/ncclRecv with ranks rank-1 and rank+1 inside one ncclGroup on a communication stream of the
+ *          context's own (librccl is loaded at run time by the first sph_comm_unique_id / sph_slab_attach_rccl);
+ *   LOCAL  the neighbours are contexts of the same process (several slabs on one GPU, tests): device copies.
+ * Protocol per step, one host wait in all:
+ *   sph_slab_step_begin   sort and search over own + received particles; force pass over the columns next to the
+ *                         faces; records for the NEXT step packed from them and posted on the communication stream;
+ *                         force pass over the interior columns meanwhile on the compute stream.  Asynchronous.
+ *   sph_slab_step_end     waits for the exchange only (counts arrive in pinned host memory), sends the remainder of a
+ *                         message that outgrew its agreed size, and queues the received records behind the interior
+ *                         force pass.  Afterwards sph_num_particles is exact and the next step may begin.
+ * With several contexts in one process call begin on all of them, then end on all of them.  Before the first step,
+ * and after anything that replaces the particle set, sph_slab_halo_begin/_end exchange the halo of the state as it
+ * stands.  rec_capacity (records per message, the same on every rank, at most 2^31/28) bounds what one face can send
+ * per step: SPH_ERR_CAPACITY beyond.  Results are bit-identical to the pack/append protocol and to a single context.
+ * The face ranges are sph_slab_set_face_shift (+3) columns wide - pass the largest sph_slab_max_column_shift of all
+ * slabs; sph_slab_missed counts interior particles that reached a neighbour's halo anyway (must stay 0). */
+int sph_comm_unique_id(void* id128);  /* 128 bytes, made on one rank and handed to all (any out-of-band channel) */
+int sph_slab_attach_rccl(sph_context* ctx, const void* id128, int rank, int nranks, int rec_capacity);
+int sph_slab_attach_local(sph_context* ctx, sph_context* left, sph_context* right, int rec_capacity);
+int sph_slab_halo_begin(sph_context* ctx);
+int sph_slab_halo_end(sph_context* ctx);
+int sph_slab_halo_exchange(sph_context* ctx); /* begin + end: one context per process */
+int sph_slab_step_begin(sph_context* ctx);
+int sph_slab_step_end(sph_context* ctx);
+int sph_slab_exchange_step(sph_context* ctx); /* begin + end: one context per process */
+/* Faces for the records of the next sph_slab_step_begin and for every step after it (load balancing): all ranks
+ * must call it between the same two steps; a face moves by at most one column per step. */
+int sph_slab_set_next_columns(sph_context* ctx, int col_lo, int col_hi);
+int sph_slab_set_face_shift(sph_context* ctx, float columns);
+int sph_slab_missed(sph_context* ctx, int64_t* missed);
 
 /* The HIP stream (hipStream_t) all of the context's work is issued on; sph_set_stream makes the
  * context issue on a caller-owned stream instead (e.g. the stream a communication library

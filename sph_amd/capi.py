@@ -49,6 +49,7 @@ _SIGNATURES = [
     ("sph_slab_get_columns", C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("sph_slab_upload", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("sph_slab_download", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("sph_slab_last_own", C.c_int, [_CTX]),
     ("sph_slab_download_debug", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("sph_slab_pack", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("sph_slab_append", C.c_int, [_CTX, C.c_void_p, C.c_int]),
@@ -56,6 +57,18 @@ _SIGNATURES = [
     ("sph_slab_lost", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     ("sph_slab_max_column_shift", C.c_int, [_CTX, C.POINTER(C.c_float)]),
     ("sph_slab_load_info", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ("sph_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("sph_slab_attach_rccl", C.c_int, [_CTX, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("sph_slab_attach_local", C.c_int, [_CTX, _CTX, _CTX, C.c_int]),
+    ("sph_slab_halo_begin", C.c_int, [_CTX]),
+    ("sph_slab_halo_end", C.c_int, [_CTX]),
+    ("sph_slab_halo_exchange", C.c_int, [_CTX]),
+    ("sph_slab_step_begin", C.c_int, [_CTX]),
+    ("sph_slab_step_end", C.c_int, [_CTX]),
+    ("sph_slab_exchange_step", C.c_int, [_CTX]),
+    ("sph_slab_set_next_columns", C.c_int, [_CTX, C.c_int, C.c_int]),
+    ("sph_slab_set_face_shift", C.c_int, [_CTX, C.c_float]),
+    ("sph_slab_missed", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
     ("sph_stream_wait", C.c_int, [_CTX, C.c_void_p]),
@@ -216,6 +229,13 @@ class Simulation:
         return {k: getattr(t, k) for k, _ in SphTimings._fields_}
 
 
+def comm_unique_id():
+    """128 opaque bytes identifying a new RCCL communicator: make them on one rank, hand them to all."""
+    buf = (C.c_char * 128)()
+    _check(load().sph_comm_unique_id(buf))
+    return bytes(buf)
+
+
 def global_cells(params):
     n = C.c_int()
     _check(load().sph_global_cells(C.byref(params), C.byref(n)))
@@ -297,7 +317,7 @@ class SlabSimulation:
         cell = np.empty(cap, np.int32)
         _check(self.lib.sph_slab_download_debug(self._ctx, rho.ctypes.data, f.ctypes.data, nc.ctypes.data,
                                                 cell.ctypes.data, cap))
-        n = self.n
+        n = int(self.lib.sph_slab_last_own(self._ctx))  # the particles the last step advanced
         return rho[:n], f[:n], nc[:n], cell[:n]
 
     def lost(self):
@@ -342,6 +362,41 @@ class SlabSimulation:
 
     def use_stream(self, stream_ptr):
         _check(self.lib.sph_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    # -- exchange issued by the library -----------------------------------------------------------------
+    def attach_rccl(self, unique_id, rank, nranks, rec_capacity=None):
+        """unique_id: the 128 bytes of sph_amd.capi.comm_unique_id(), made on one rank and handed to all."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _check(self.lib.sph_slab_attach_rccl(self._ctx, buf, int(rank), int(nranks),
+                                             int(rec_capacity or self.rec_capacity)))
+
+    def attach_local(self, left, right, rec_capacity=None):
+        _check(self.lib.sph_slab_attach_local(self._ctx, left._ctx if left is not None else None,
+                                              right._ctx if right is not None else None,
+                                              int(rec_capacity or self.rec_capacity)))
+
+    def halo_begin(self):
+        _check(self.lib.sph_slab_halo_begin(self._ctx))
+
+    def halo_end(self):
+        _check(self.lib.sph_slab_halo_end(self._ctx))
+
+    def step_begin(self):
+        _check(self.lib.sph_slab_step_begin(self._ctx))
+
+    def step_end(self):
+        _check(self.lib.sph_slab_step_end(self._ctx))
+
+    def set_next_columns(self, lo, hi):
+        _check(self.lib.sph_slab_set_next_columns(self._ctx, int(lo), int(hi)))
+
+    def set_face_shift(self, columns):
+        _check(self.lib.sph_slab_set_face_shift(self._ctx, float(columns)))
+
+    def missed(self):
+        v = C.c_int64()
+        _check(self.lib.sph_slab_missed(self._ctx, C.byref(v)))
+        return v.value
 
     def empty_records(self, n):
         return self.torch.empty((n, RECORD_WORDS), dtype=self.torch.float32, device=self.device)

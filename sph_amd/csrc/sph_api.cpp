@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "sph_internal.hpp"
+#include "sph_rccl.hpp"
 
 using namespace sph;
 
@@ -78,6 +79,25 @@ struct sph_context {
   bool pre_side[2] = {false, false};  // which faces the caller packs for (as of its last sph_slab_pack)
   bool pre_valid = false;             // pre_rec and h_counters[0..1] describe the current `cur` and cuts
   int64_t lost = 0;
+  // ---- exchange driven by the library (overlapped slab step) ----
+  enum { XFER_NONE = 0, XFER_RCCL = 1, XFER_LOCAL = 2 };
+  int xfer = XFER_NONE;
+  void* rccl = nullptr;                    // ncclComm_t
+  int rank = -1, nranks = 0;
+  sph_context* peer[2] = {nullptr, nullptr};  // local transport: the neighbouring contexts of this process (left, right)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+  int xcap = 0;                            // records a message buffer holds behind its header record
+  float* msg_out[2] = {nullptr, nullptr};  // [(xcap + 1) records] message to the left / right neighbour
+  float* msg_in[2] = {nullptr, nullptr};   // message from the left / right neighbour
+  int cap_out[2] = {0, 0}, cap_in[2] = {0, 0};  // records the next message to / from each neighbour holds (agreed sizes)
+  bool halo_current = false;               // `cur` holds own particles AND the neighbours' records for the next sort
+  bool in_flight = false;                  // a begin() has posted an exchange that no end() has completed yet
+  uint64_t begun = 0;                      // exchanges posted so far (LOCAL transport: a neighbour must have kept up)
+  bool next_pending = false;
+  int next_lo = 0, next_hi = 0;            // faces the NEXT exchange packs for (set_next_columns)
+  float face_shift = 4.0f;                 // columns a particle may cross per step: how wide the face ranges are
+  int64_t missed = 0;
   bool timing = false;
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
@@ -280,9 +300,13 @@ int set_grid(sph_context* c, const sph_params* p, int col_lo, int col_hi) {
   if (ncells > c->cell_capacity)
     return fail(SPH_ERR_CAPACITY, "local grid of %d x %d x %d cells exceeds the context's capacity of %zu cells", nx,
                 gn, gn, c->cell_capacity);
+  if (c->gn != gn || c->col_lo != col_lo || c->col_hi != col_hi || c->dev.cell != resolved_cell(p))
+    c->halo_current = false;  // other cells or other faces: the neighbours' records held no longer fit
   derive(p, nx, g_lo, gn, &c->dev);
   c->dev.own_lo = col_lo - g_lo;
   c->dev.own_hi = col_hi - g_lo;
+  c->dev.force_lo = c->dev.own_lo;
+  c->dev.force_hi = c->dev.own_hi;
   c->dev.dens_lo = c->dev.own_lo > 0 ? c->dev.own_lo - 1 : 0;
   c->dev.dens_hi = c->dev.own_hi < nx ? c->dev.own_hi + 1 : nx;
   c->grid.ncells = ncells;
@@ -340,6 +364,7 @@ int one_step(sph_context* c) {
   if (c->slab) {
     // ghosts and emigrants drop out here: only own-column particles were written back
     c->pre_valid = false;
+    c->halo_current = false;
     if (c->pre_cap > 0) {
       const bool has_left = c->col_lo > 0 && c->pre_side[0], has_right = c->col_hi < c->gn && c->pre_side[1];
       HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
@@ -413,9 +438,9 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
       (rc = dev_alloc(heap, (uint32_t**)&c->stage_dbg, 6 * n)) || (rc = dev_alloc(heap, &c->d_counters, 8)) ||
       (rc = dev_alloc(heap, &c->d_colcounts, (size_t)cap_cols + 4)))
     return bail(rc);
-  if (hipHostMalloc((void**)&c->h_counters, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+  if (hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipHostMalloc failed"));
-  memset(c->h_counters, 0, 8 * sizeof(int32_t));
+  memset(c->h_counters, 0, 16 * sizeof(int32_t));
   if (hipMemsetAsync(c->grid.count, 0, padded * sizeof(int32_t), c->stream) != hipSuccess ||
       hipMemsetAsync(c->d_counters, 0, 8 * sizeof(int32_t), c->stream) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipMemsetAsync failed"));
@@ -477,6 +502,11 @@ int sph_destroy(sph_context* c) {
   (void)hipFree(c->stage_pos); (void)hipFree(c->stage_vel); (void)hipFree(c->stage_dbg);
   (void)hipFree(c->d_counters); (void)hipFree(c->d_colcounts);
   (void)hipFree(c->pre_rec[0]); (void)hipFree(c->pre_rec[1]);
+  for (int k = 0; k < 2; k++) { (void)hipFree(c->msg_out[k]); (void)hipFree(c->msg_in[k]); }
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+  if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+  if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+  if (c->rccl) rccl_comm_destroy(c->rccl);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -514,6 +544,7 @@ static int upload_common(sph_context* c, const float* pos, const float* vel, int
   c->uploaded = true;
   c->stepped = false;
   c->pre_valid = false;
+  c->halo_current = false;
   return SPH_OK;
 }
 
@@ -620,6 +651,12 @@ int sph_num_particles(const sph_context* c) {
   return c->n;
 }
 
+int sph_slab_last_own(const sph_context* c) {
+  if (!c) return 0;
+  if (c->n_pending) (void)resolve_n(const_cast<sph_context*>(c));
+  return c->n_last_own;
+}
+
 int sph_grid_dims(const sph_context* c, int dims[3]) {
   if (!c || !dims) return fail(SPH_ERR_INVALID, "NULL argument");
   dims[0] = c->dev.nx;
@@ -714,6 +751,7 @@ int sph_slab_upload(sph_context* c, const float* pos, const float* vel, const in
   c->uploaded = true;
   c->stepped = false;
   c->pre_valid = false;
+  c->halo_current = false;
   return SPH_OK;
 }
 
@@ -912,6 +950,359 @@ int sph_slab_max_column_shift(sph_context* c, float* columns) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(columns, c->h_counters + 5, sizeof(float));
   return SPH_OK;
+}
+
+
+// ---- exchange driven by the library: overlapped slab step ---------------------------------------------------------------
+// The reference has no counterpart (single process).  A slab context that has been attached to a transport exchanges
+// its halo and migration records itself:
+//   transport RCCL   ncclSend/ncclRecv with the two neighbouring ranks inside one ncclGroup, on the context's own
+//                    communication stream (xGMI: each neighbour pair has its own direct link; no collective);
+//   transport LOCAL  the neighbours are contexts of the same process (several slabs on one GPU, tests): a device copy
+//                    out of the neighbour's message buffer, ordered by events.
+// A message holds an agreed number of records behind a header record whose first word is the sender's true count:
+// both ends size the next message from the last true count (the sender knows what it sent, the receiver what it got),
+// so sizes are known at both ends without a handshake, and the rare message that outgrows its size sends the
+// remainder in a second round.
+namespace {
+
+constexpr int kHdr = 1;  // header records in front of a message
+
+int next_capacity(int count, int xcap) {
+  long long want = (long long)count + count / 4 + 1;  // + 25 %
+  want = (want + 255) / 256 * 256;
+  if (want < 1024) want = 1024;
+  return (int)(want > xcap ? xcap : want);
+}
+
+bool has_face(const sph_context* c, int side, bool next) {
+  const int lo = next && c->next_pending ? c->next_lo : c->col_lo, hi = next && c->next_pending ? c->next_hi : c->col_hi;
+  return side == 0 ? lo > 0 : hi < c->gn;
+}
+
+int attach_common(sph_context* c, int rec_capacity) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->slab) return fail(SPH_ERR_STATE, "not a slab context");
+  if (c->xfer != sph_context::XFER_NONE) return fail(SPH_ERR_STATE, "the context is already attached to a transport");
+  if (rec_capacity < 1024) return fail(SPH_ERR_INVALID, "rec_capacity must be at least 1024 records");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+  const size_t bytes = (size_t)(rec_capacity + kHdr) * kRecordBytes;
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipMalloc((void**)&c->msg_out[k], bytes));
+    HIP_TRY(hipMalloc((void**)&c->msg_in[k], bytes));
+  }
+  c->xcap = rec_capacity;
+  c->halo_current = false;
+  // an event that has never been recorded counts as complete: the first waits on ev_comm pass
+  return SPH_OK;
+}
+
+// Posts the exchange of the messages in msg_out (packed and headed on the compute stream, ev_pack recorded behind
+// them) with `cap[side]` records each way.  RCCL: enqueued on the communication stream.  LOCAL: nothing to post - the
+// neighbour fetches the message in its complete_exchange.
+int post_exchange(sph_context* c, const int cap_out[2], const int cap_in[2]) {
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+  if (c->xfer == sph_context::XFER_RCCL) {
+    char err[256] = "";
+    const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
+    const size_t w = SPH_SLAB_RECORD_WORDS;
+    if (rccl_exchange(c->rccl, c->comm_stream, l ? c->rank - 1 : -1, c->msg_out[0], (size_t)(cap_out[0] + kHdr) * w,
+                      c->msg_in[0], (size_t)(cap_in[0] + kHdr) * w, r ? c->rank + 1 : -1, c->msg_out[1],
+                      (size_t)(cap_out[1] + kHdr) * w, c->msg_in[1], (size_t)(cap_in[1] + kHdr) * w, err, sizeof err))
+      return fail(SPH_ERR_HIP, "halo exchange: %s", err);
+    if (l) HIP_TRY(hipMemcpyAsync(c->h_counters + 8, c->msg_in[0], sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
+    if (r) HIP_TRY(hipMemcpyAsync(c->h_counters + 9, c->msg_in[1], sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
+  }
+  // own count, trash count, what was packed, stray and missed counters: one small copy behind the exchange
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
+  if (c->xfer == sph_context::XFER_RCCL) HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+  c->in_flight = true;
+  c->begun += 1;
+  return SPH_OK;
+}
+
+// Completes the exchange: the ONE host wait of a step (on the communication stream; the compute stream keeps running
+// the interior force pass), then the received records join the particle set behind the own particles.
+// `own_known` >= 0: the own count is that (halo exchange of an uploaded state); < 0: it comes home with the counters.
+int complete_exchange(sph_context* c, int own_known) {
+  const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
+  const bool face[2] = {l, r};
+  int n_in[2] = {0, 0};
+  if (c->xfer == sph_context::XFER_LOCAL) {
+    // the neighbour's message for me is its msg_out on the side facing me; its header count sits in its counters
+    for (int k = 0; k < 2; k++) {
+      if (!face[k]) continue;
+      sph_context* p = c->peer[k];
+      if (!p || p->begun < c->begun) return fail(SPH_ERR_STATE, "the neighbouring context has not begun this exchange");
+      HIP_TRY(hipStreamWaitEvent(c->comm_stream, p->ev_pack, 0));
+      HIP_TRY(hipMemcpyAsync(c->h_counters + 8 + k, p->d_counters + (1 - k), sizeof(int32_t), hipMemcpyDeviceToHost,
+                             c->comm_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    for (int k = 0; k < 2; k++) {
+      if (!face[k]) continue;
+      n_in[k] = c->h_counters[8 + k];
+      if (n_in[k] > c->xcap)
+        return fail(SPH_ERR_CAPACITY, "%d halo/migration records exceed the message capacity %d", n_in[k], c->xcap);
+      if (n_in[k] > 0)
+        HIP_TRY(hipMemcpyAsync(c->msg_in[k] + kHdr * SPH_SLAB_RECORD_WORDS,
+                               c->peer[k]->msg_out[1 - k] + kHdr * SPH_SLAB_RECORD_WORDS,
+                               (size_t)n_in[k] * kRecordBytes, hipMemcpyDeviceToDevice, c->comm_stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+  } else {
+    HIP_TRY(hipEventSynchronize(c->ev_comm));
+    int n_out[2] = {c->h_counters[0], c->h_counters[1]};
+    for (int k = 0; k < 2; k++) n_in[k] = face[k] ? c->h_counters[8 + k] : 0;
+    for (int k = 0; k < 2; k++)
+      if (n_in[k] > c->xcap || n_out[k] > c->xcap)
+        return fail(SPH_ERR_CAPACITY, "%d halo/migration records exceed the message capacity %d",
+                    n_in[k] > n_out[k] ? n_in[k] : n_out[k], c->xcap);
+    // remainders of messages that outgrew their agreed size: exact sizes are now known at both ends
+    const int more_out[2] = {face[0] && n_out[0] > c->cap_out[0] ? n_out[0] - c->cap_out[0] : 0,
+                             face[1] && n_out[1] > c->cap_out[1] ? n_out[1] - c->cap_out[1] : 0};
+    const int more_in[2] = {n_in[0] > c->cap_in[0] ? n_in[0] - c->cap_in[0] : 0,
+                            n_in[1] > c->cap_in[1] ? n_in[1] - c->cap_in[1] : 0};
+    if (more_out[0] || more_out[1] || more_in[0] || more_in[1]) {
+      char err[256] = "";
+      const size_t w = SPH_SLAB_RECORD_WORDS;
+      if (rccl_exchange(c->rccl, c->comm_stream, l ? c->rank - 1 : -1, c->msg_out[0] + (size_t)(c->cap_out[0] + kHdr) * w,
+                        (size_t)more_out[0] * w, c->msg_in[0] + (size_t)(c->cap_in[0] + kHdr) * w, (size_t)more_in[0] * w,
+                        r ? c->rank + 1 : -1, c->msg_out[1] + (size_t)(c->cap_out[1] + kHdr) * w, (size_t)more_out[1] * w,
+                        c->msg_in[1] + (size_t)(c->cap_in[1] + kHdr) * w, (size_t)more_in[1] * w, err, sizeof err))
+        return fail(SPH_ERR_HIP, "halo exchange (remainder): %s", err);
+      HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+    }
+    for (int k = 0; k < 2; k++) {
+      c->cap_out[k] = next_capacity(n_out[k], c->xcap);
+      c->cap_in[k] = next_capacity(n_in[k], c->xcap);
+    }
+  }
+  const int own = own_known >= 0 ? own_known : c->h_counters[2];
+  c->lost = c->h_counters[4];
+  c->missed = c->h_counters[6];
+  if ((long long)own + n_in[0] + n_in[1] > c->n_max)
+    return fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", own, n_in[0] + n_in[1], c->n_max);
+  // the received records join the set on the compute stream, behind whatever it is still doing
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+  c->n = own;
+  c->n_last_own = own;
+  c->n_pending = false;
+  for (int k = 0; k < 2; k++) {
+    if (n_in[k] <= 0) continue;
+    Timed t(c, CAT_OTHER);
+    launch_slab_append(c->stream, c->dev, c->msg_in[k] + kHdr * SPH_SLAB_RECORD_WORDS, n_in[k], c->cur, c->n,
+                       c->d_counters + 4);
+    c->n += n_in[k];
+  }
+  HIP_TRY(hipGetLastError());
+  c->in_flight = false;
+  c->halo_current = true;
+  return SPH_OK;
+}
+
+// LOCAL transport: my next pack overwrites msg_out, which the neighbours copy from in THEIR complete_exchange.
+int wait_for_readers(sph_context* c) {
+  if (c->xfer != sph_context::XFER_LOCAL) return SPH_OK;
+  for (int k = 0; k < 2; k++)
+    if (c->peer[k] && c->peer[k]->ev_comm) HIP_TRY(hipStreamWaitEvent(c->stream, c->peer[k]->ev_comm, 0));
+  return SPH_OK;
+}
+
+}  // namespace
+
+int sph_comm_unique_id(void* id128) {
+  if (!id128) return fail(SPH_ERR_INVALID, "NULL argument");
+  char err[256] = "";
+  if (rccl_unique_id(id128, err, sizeof err)) return fail(SPH_ERR_HIP, "%s", err);
+  return SPH_OK;
+}
+
+int sph_slab_attach_rccl(sph_context* c, const void* id128, int rank, int nranks, int rec_capacity) {
+  if (!id128 || rank < 0 || rank >= nranks) return fail(SPH_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+  int rc = attach_common(c, rec_capacity);
+  if (rc) return rc;
+  char err[256] = "";
+  if (rccl_comm_create(&c->rccl, id128, rank, nranks, err, sizeof err)) return fail(SPH_ERR_HIP, "%s", err);
+  c->rank = rank;
+  c->nranks = nranks;
+  c->xfer = sph_context::XFER_RCCL;
+  return SPH_OK;
+}
+
+int sph_slab_attach_local(sph_context* c, sph_context* left, sph_context* right, int rec_capacity) {
+  int rc = attach_common(c, rec_capacity);
+  if (rc) return rc;
+  c->peer[0] = left;
+  c->peer[1] = right;
+  c->xfer = sph_context::XFER_LOCAL;
+  return SPH_OK;
+}
+
+int sph_slab_set_next_columns(sph_context* c, int col_lo, int col_hi) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->slab) return fail(SPH_ERR_STATE, "not a slab context");
+  if (col_lo < 0 || col_hi > c->gn || col_hi - col_lo < SPH_SLAB_MIN_COLUMNS)
+    return fail(SPH_ERR_INVALID, "slab columns [%d, %d) invalid", col_lo, col_hi);
+  if (col_hi - col_lo > c->cols_capacity)
+    return fail(SPH_ERR_CAPACITY, "%d columns exceed cols_capacity = %d", col_hi - col_lo, c->cols_capacity);
+  if (abs(col_lo - c->col_lo) > 1 || abs(col_hi - c->col_hi) > 1)
+    return fail(SPH_ERR_INVALID, "a face may move by at most one column per step");
+  c->next_lo = col_lo;
+  c->next_hi = col_hi;
+  c->next_pending = col_lo != c->col_lo || col_hi != c->col_hi;
+  return SPH_OK;
+}
+
+int sph_slab_set_face_shift(sph_context* c, float columns) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!(columns >= 0.0f) || columns > 1024.0f) return fail(SPH_ERR_INVALID, "bad column shift %g", columns);
+  c->face_shift = columns;
+  return SPH_OK;
+}
+
+int sph_slab_missed(sph_context* c, int64_t* missed) {
+  if (!c || !missed) return fail(SPH_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->h_counters + 6, c->d_counters + 6, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->missed = c->h_counters[6];
+  *missed = c->missed;
+  return SPH_OK;
+}
+
+// Halo exchange of the state as it stands (after an upload): every particle near a face is packed.
+int sph_slab_halo_begin(sph_context* c) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (c->xfer == sph_context::XFER_NONE) return fail(SPH_ERR_STATE, "attach a transport first");
+  if (!c->uploaded) return fail(SPH_ERR_STATE, "halo exchange before upload");
+  if (c->in_flight) return fail(SPH_ERR_STATE, "an exchange is already in flight");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc) return rc;
+  if ((rc = wait_for_readers(c))) return rc;
+  c->next_pending = false;
+  const bool l = has_face(c, 0, false), r = has_face(c, 1, false);
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
+  {
+    Timed t(c, CAT_OTHER);
+    launch_slab_pack(c->stream, c->dev, c->cur, c->n, nullptr, c->col_lo, c->col_hi, l, r,
+                     c->msg_out[0] + kHdr * SPH_SLAB_RECORD_WORDS, c->msg_out[1] + kHdr * SPH_SLAB_RECORD_WORDS, c->xcap,
+                     c->d_counters);
+    launch_slab_headers(c->stream, c->d_counters, l ? c->msg_out[0] : nullptr, r ? c->msg_out[1] : nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_pack, c->stream));
+  // first message of a run: full-size both ways (every rank uses the same rec_capacity)
+  c->cap_out[0] = c->cap_out[1] = c->cap_in[0] = c->cap_in[1] = c->xcap;
+  return post_exchange(c, c->cap_out, c->cap_in);
+}
+
+int sph_slab_halo_end(sph_context* c) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->in_flight) return fail(SPH_ERR_STATE, "no exchange in flight");
+  HIP_TRY(hipSetDevice(c->device));
+  return complete_exchange(c, c->n);
+}
+
+// One time step, records for the next one packed and under way before the interior columns are advanced.
+int sph_slab_step_begin(sph_context* c) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (c->xfer == sph_context::XFER_NONE) return fail(SPH_ERR_STATE, "attach a transport first");
+  if (!c->halo_current) return fail(SPH_ERR_STATE, "the halo is not current: sph_slab_halo_begin/end first");
+  if (c->in_flight) return fail(SPH_ERR_STATE, "an exchange is already in flight");
+  if (c->params.flags & (SPH_FLAG_EXACT_ORDER | SPH_FLAG_LANE_SWEEP))
+    return fail(SPH_ERR_STATE, "the overlapped step runs the masked sweeps only");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  const bool keep = (c->params.flags & SPH_FLAG_KEEP_DEBUG) != 0;
+  const SweepMode mode = (c->params.flags & SPH_FLAG_REFERENCE_ARITH) ? SWEEP_MASKED : SWEEP_FAST;
+  const int n = c->n;
+  { Timed t(c, CAT_HASH); launch_hash(c->stream, c->dev, c->cur, n, c->grid); }
+  { Timed t(c, CAT_SCAN); launch_scan(c->stream, c->grid); }
+  { Timed t(c, CAT_REORDER); launch_reorder(c->stream, c->cur, c->sorted, n, c->grid); }
+  { Timed t(c, CAT_SEARCH);
+    launch_neighbours(c->stream, c->dev, c->sorted, n, c->grid, c->nmask, mode == SWEEP_FAST, keep ? c->dbg.ncount : nullptr); }
+  if (mode != SWEEP_FAST) {
+    Timed t(c, CAT_DENSITY);
+    launch_density(c->stream, c->dev, c->sorted, n, c->grid, keep ? c->dbg.ncount : nullptr, c->nmask, mode);
+  }
+  // face ranges (local columns): wide enough that whatever can reach the neighbour's halo within this step, and the
+  // column a face may move by, starts inside them
+  const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
+  const int width = 3 + (int)ceilf(c->face_shift) + (c->next_pending ? 1 : 0);
+  const DevParams& G = c->dev;
+  const int a_lo = G.own_lo, a_hi = l ? (G.own_lo + width < G.own_hi ? G.own_lo + width : G.own_hi) : G.own_lo;
+  const int b_hi = G.own_hi, b_lo = r ? (G.own_hi - width > a_hi ? G.own_hi - width : a_hi) : G.own_hi;
+  const int send_lo = c->next_pending ? c->next_lo : c->col_lo, send_hi = c->next_pending ? c->next_hi : c->col_hi;
+  int32_t* own_out = c->d_counters + 2;
+  auto force_range = [&](int lo, int hi) {
+    if (hi <= lo && own_out == nullptr) return;
+    DevParams Q = c->dev;
+    Q.force_lo = lo;
+    Q.force_hi = hi;
+    Timed t(c, CAT_FORCE);
+    launch_force(c->stream, Q, c->sorted, c->cur, n, c->grid, keep ? c->dbg.force : nullptr, own_out, c->nmask, mode);
+    own_out = nullptr;  // the first launch reports the own and trash counts
+  };
+  if ((rc = wait_for_readers(c))) return rc;
+  force_range(a_lo, a_hi);
+  if (b_hi > b_lo) force_range(b_lo, b_hi);
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
+  {
+    Timed t(c, CAT_OTHER);
+    launch_slab_pack_faces(c->stream, c->dev, c->cur, n, c->grid.start, a_lo, a_hi, b_lo, b_hi, send_lo, send_hi, l, r,
+                           c->msg_out[0], c->msg_out[1], c->xcap, c->d_counters);
+    launch_slab_headers(c->stream, c->d_counters, l ? c->msg_out[0] : nullptr, r ? c->msg_out[1] : nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_pack, c->stream));
+  if ((rc = post_exchange(c, c->cap_out, c->cap_in))) return rc;
+  // the interior columns, while the records travel
+  if (b_lo > a_hi) {
+    force_range(a_hi, b_lo);
+    launch_slab_check_interior(c->stream, c->dev, c->cur, n, c->grid.start, a_hi, b_lo, send_lo, send_hi, l, r,
+                               c->d_counters + 6);
+  }
+  HIP_TRY(hipGetLastError());
+  c->dbg_stride = n;
+  c->sorted_dev = c->dev;
+  c->sorted_col_lo = c->col_lo;
+  c->sorted_col_hi = c->col_hi;
+  c->pre_valid = false;
+  c->halo_current = false;
+  c->stepped = true;
+  c->acc_steps += 1;
+  c->acc_particles += (uint64_t)n;
+  if (c->pending.size() > 8192) return drain_timings(c);
+  return SPH_OK;
+}
+
+int sph_slab_step_end(sph_context* c) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!c->in_flight) return fail(SPH_ERR_STATE, "no exchange in flight");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = complete_exchange(c, -1);
+  if (rc) return rc;
+  if (c->next_pending) {  // the records just exchanged were packed for the new faces: they take effect now
+    c->next_pending = false;
+    rc = set_grid(c, &c->params, c->next_lo, c->next_hi);
+    c->halo_current = rc == SPH_OK;
+  }
+  return rc;
+}
+
+int sph_slab_exchange_step(sph_context* c) {
+  int rc = sph_slab_step_begin(c);
+  return rc ? rc : sph_slab_step_end(c);
+}
+
+int sph_slab_halo_exchange(sph_context* c) {
+  int rc = sph_slab_halo_begin(c);
+  return rc ? rc : sph_slab_halo_end(c);
 }
 
 int sph_get_stream(sph_context* c, void** stream) {

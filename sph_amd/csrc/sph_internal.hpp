@@ -22,6 +22,8 @@ struct DevParams {
   int cx_off;                // global x-column of local column 0 (slab decomposition)
   int gnx;                   // global cells per axis (for clamping before the offset)
   int own_lo, own_hi;        // local x-columns this context integrates: [own_lo, own_hi)
+  int force_lo, force_hi;    // local x-columns one launch of the force pass advances: all own columns, or a part of them
+                             // (faces first, interior while the halo records travel)
   int dens_lo, dens_hi;      // local x-columns whose density is needed: own plus one ghost column per side
   int tension;               // surface-tension term on/off
   int xcd_run;               // consecutive workgroups of a sweep that share an XCD (set by the sweep launchers)
@@ -112,6 +114,17 @@ void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const Sta
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, const int32_t* n_dev, int col_lo,
                       int col_hi, bool has_left, bool has_right, float* rec_left, float* rec_right, int cap,
                       int32_t* counters);
+// Overlapped slab step: records from the freshly advanced particles of the local columns [a_lo, a_hi) and [b_lo, b_hi)
+// only (the columns next to the faces), written behind a header record that carries the count; and the check that no
+// particle of the remaining own columns ended up where a neighbour would have needed it.
+void launch_slab_pack_faces(hipStream_t s, const DevParams& P, const State& st, int n_bound, const int32_t* start,
+                            int a_lo, int a_hi, int b_lo, int b_hi, int col_lo, int col_hi, bool has_left,
+                            bool has_right, float* msg_left, float* msg_right, int cap, int32_t* counters);
+void launch_slab_headers(hipStream_t s, const int32_t* counters, float* msg_left, float* msg_right);
+void launch_slab_check_interior(hipStream_t s, const DevParams& P, const State& st, int n_bound, const int32_t* start,
+                                int lo, int hi, int col_lo, int col_hi, bool has_left, bool has_right,
+                                int32_t* missed);
+
 void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int n_rec, const State& st, int at,
                         int32_t* stray);
 void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out);

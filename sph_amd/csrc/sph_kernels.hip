@@ -282,6 +282,69 @@ __global__ void k_slab_pack(DevParams P, State st, int n, const int32_t* __restr
   }
 }
 
+// Overlapped slab step.  The force pass advances the columns next to the faces first; this kernel then packs records
+// from exactly those freshly written particles - the local columns [a_lo, a_hi) and [b_lo, b_hi), disjoint - while the
+// interior columns are still being advanced.  Records go behind a header record (record 0 of each message; its first
+// word receives the count from k_slab_headers).  `st` is the NEW state: own slot s of the last sort sits at index
+// s - (first own slot).  Faces: [col_lo, col_hi) in global columns, the ones the NEXT step will use.
+__global__ void k_slab_pack_faces(DevParams P, State st, const int32_t* __restrict__ start, int a_lo, int a_hi, int b_lo,
+                                  int b_hi, int col_lo, int col_hi, int has_left, int has_right,
+                                  float* __restrict__ msg_left, float* __restrict__ msg_right, int cap,
+                                  int32_t* __restrict__ counters) {
+  const int cpc = P.ny * P.nz;
+  const int own_base = start[P.own_lo * cpc];
+  const int a0 = start[a_lo * cpc], a1 = start[a_hi * cpc], b0 = start[b_lo * cpc], b1 = start[b_hi * cpc];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int s;
+  if (i < a1 - a0) {
+    s = a0 + i;
+  } else {
+    i -= a1 - a0;
+    if (i >= b1 - b0) return;
+    s = b0 + i;
+  }
+  const int o = s - own_base;
+  int g = cell_coord(st.x[o], P.cell, P.gnx);
+  bool to_left = has_left && g < col_lo + 2;
+  bool to_right = has_right && g >= col_hi - 2;
+  if (!to_left && !to_right) return;
+  float r[kRecWords] = {st.x[o], st.y[o], st.z[o], st.vx[o], st.vy[o], st.vz[o], __int_as_float(st.id[o])};
+  if (to_left) {
+    int k = atomicAdd(&counters[0], 1);
+    if (k < cap)
+      for (int w = 0; w < kRecWords; w++) msg_left[(size_t)(k + 1) * kRecWords + w] = r[w];
+  }
+  if (to_right) {
+    int k = atomicAdd(&counters[1], 1);
+    if (k < cap)
+      for (int w = 0; w < kRecWords; w++) msg_right[(size_t)(k + 1) * kRecWords + w] = r[w];
+  }
+}
+
+// Header record of each message: word 0 = number of records the sender has for this neighbour (bit-cast int; may
+// exceed what the message holds, in which case the remainder follows in a second message).
+__global__ void k_slab_headers(const int32_t* __restrict__ counters, float* __restrict__ msg_left,
+                               float* __restrict__ msg_right) {
+  if (threadIdx.x == 0 && msg_left) msg_left[0] = __int_as_float(counters[0]);
+  if (threadIdx.x == 1 && msg_right) msg_right[0] = __int_as_float(counters[1]);
+}
+
+// The interior columns [lo, hi) were advanced after the records had been packed: none of their particles may have
+// ended up within two columns of a face or beyond it (the neighbour would have needed a record of it).  Counts the
+// ones that did; the caller widens the face ranges when this is not zero.
+__global__ void k_slab_check_interior(DevParams P, State st, const int32_t* __restrict__ start, int lo, int hi,
+                                      int col_lo, int col_hi, int has_left, int has_right,
+                                      int32_t* __restrict__ missed) {
+  const int cpc = P.ny * P.nz;
+  const int own_base = start[P.own_lo * cpc];
+  const int s0 = start[lo * cpc], s1 = start[hi * cpc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s1 - s0) return;
+  const int o = s0 + i - own_base;
+  const int g = cell_coord(st.x[o], P.cell, P.gnx);
+  if ((has_left && g < col_lo + 2) || (has_right && g >= col_hi - 2)) atomicAdd(missed, 1);
+}
+
 // Received records join the particle set.  A record whose x-column lies outside this context's local grid
 // (own columns +- 2) can be neither integrated nor used as a ghost here and nobody else holds it: it is counted
 // in *stray (the slabs are too narrow for the distance particles travel per step).
@@ -406,6 +469,26 @@ void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n,
   if (n <= 0) return;
   hipLaunchKernelGGL(k_slab_pack, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, n_dev, col_lo, col_hi,
                      has_left ? 1 : 0, has_right ? 1 : 0, rec_left, rec_right, cap, counters);
+}
+
+void launch_slab_pack_faces(hipStream_t s, const DevParams& P, const State& st, int n_bound, const int32_t* start,
+                            int a_lo, int a_hi, int b_lo, int b_hi, int col_lo, int col_hi, bool has_left,
+                            bool has_right, float* msg_left, float* msg_right, int cap, int32_t* counters) {
+  if (n_bound <= 0 || (!has_left && !has_right)) return;
+  hipLaunchKernelGGL(k_slab_pack_faces, dim3(div_up(n_bound, kBlock)), dim3(kBlock), 0, s, P, st, start, a_lo, a_hi, b_lo,
+                     b_hi, col_lo, col_hi, has_left ? 1 : 0, has_right ? 1 : 0, msg_left, msg_right, cap, counters);
+}
+
+void launch_slab_headers(hipStream_t s, const int32_t* counters, float* msg_left, float* msg_right) {
+  hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, s, counters, msg_left, msg_right);
+}
+
+void launch_slab_check_interior(hipStream_t s, const DevParams& P, const State& st, int n_bound, const int32_t* start,
+                                int lo, int hi, int col_lo, int col_hi, bool has_left, bool has_right,
+                                int32_t* missed) {
+  if (n_bound <= 0 || hi <= lo || (!has_left && !has_right)) return;
+  hipLaunchKernelGGL(k_slab_check_interior, dim3(div_up(n_bound, kBlock)), dim3(kBlock), 0, s, P, st, start, lo, hi,
+                     col_lo, col_hi, has_left ? 1 : 0, has_right ? 1 : 0, missed);
 }
 
 void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out) {

@@ -391,15 +391,18 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
   __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
-  // slots of the own x-columns [own_lo, own_hi); the new state is written compactly from index 0
-  int base, bound;
-  column_slots(P, start, P.own_lo, P.own_hi, base, bound);
+  // This launch advances the slots of the x-columns [force_lo, force_hi), a part (usually all) of the own columns
+  // [own_lo, own_hi); the new state is written compactly: own slot s goes to index s - (first own slot).
+  int base, bound, own_base, own_bound;
+  column_slots(P, start, P.force_lo, P.force_hi, base, bound);
+  column_slots(P, start, P.own_lo, P.own_hi, own_base, own_bound);
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_own_out) {
     const int real = P.nx * P.ny * P.nz;
-    n_own_out[0] = bound - base;                   // particles this context keeps
+    n_own_out[0] = own_bound - own_base;           // particles this context keeps
     n_own_out[1] = start[real + 1] - start[real];  // trash cell: particles outside the local grid
   }
   const int first = xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x;
+  if (base + first >= bound) return;  // whole block beyond the range (uniform: before any barrier)
   int col = threadIdx.x;
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
@@ -407,8 +410,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTable{rt_shift, rt_qend});
     col = lane_by_count(load);
   }
-  const int o = first + col;
-  const int s = base + o;
+  const int s = base + first + col;
+  const int o = s - own_base;
   if (s >= bound) return;
   const float4 pi4 = st.pos[s];
   const float4 vi4 = st.rec[s].vel;  // w = density

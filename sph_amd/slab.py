@@ -322,3 +322,80 @@ def rebalance_local_slabs(backends, cuts):
         for r, b in enumerate(backends):
             b.set_columns(new[r], new[r + 1])
     return new
+
+
+# ---- exchange issued by the library (sph_slab_step_begin / _end) ---------------------------------------------------------
+
+def halo_local_slabs(backends):
+    """Initial halo exchange of several attached slabs that live in ONE process: begin on all, then end on all."""
+    for b in backends:
+        b.halo_begin()
+    for b in backends:
+        b.halo_end()
+
+
+def step_local_slabs_overlapped(backends):
+    """One overlapped step of several attached slabs that live in ONE process."""
+    for b in backends:
+        b.step_begin()
+    for b in backends:
+        b.step_end()
+
+
+def rebalance_next_local_slabs(backends, cuts):
+    """Load balancing for the library-driven exchange: the new cuts apply to the records of the next step."""
+    hist = np.zeros(cuts[-1], np.int64)
+    for r, b in enumerate(backends):
+        c = b.column_counts()
+        hist[cuts[r]:cuts[r] + len(c)] = c
+    shift = max(b.max_column_shift() for b in backends)
+    new = rebalance_cuts(cuts, hist, min_cols=min_columns_for_shift(shift))
+    for r, b in enumerate(backends):
+        b.set_face_shift(shift)
+        b.set_next_columns(new[r], new[r + 1])
+    return new
+
+
+class LibraryRunner:
+    """Drives one slab per process with the exchange issued by the library (RCCL from C++, overlapped with the interior
+    columns).  torch.distributed is used only off the data path: to hand the communicator id to the ranks and to
+    all-reduce the column histogram when the cut planes are rebalanced."""
+
+    def __init__(self, backend, rank, nranks, cuts, rebalance_every=0, group=None, reduce_device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.backend, self.rank, self.nranks = backend, rank, nranks
+        self.cuts = list(cuts)
+        self.rebalance_every = rebalance_every
+        self.steps_done = 0
+        self.reduce_device = reduce_device if reduce_device is not None else torch.device("cpu")
+
+    def prime(self):
+        self.backend.halo_begin()
+        self.backend.halo_end()
+
+    def step(self):
+        b = self.backend
+        b.step_begin()
+        b.step_end()
+        self.steps_done += 1
+        if self.rebalance_every and self.steps_done % self.rebalance_every == 0 and self.nranks > 1:
+            self.rebalance()
+
+    def rebalance(self):
+        b = self.backend
+        counts, own_shift = b.load_info()
+        ncols = self.cuts[-1]
+        full = self.torch.zeros(ncols + self.nranks, dtype=self.torch.int64)
+        lo = self.cuts[self.rank]
+        full[lo:lo + len(counts)] = self.torch.as_tensor(np.asarray(counts, dtype=np.int64))
+        full[ncols + self.rank] = int(np.ceil(float(own_shift) * 1024.0))
+        full = full.to(self.reduce_device)
+        self.dist.all_reduce(full, group=self.group)
+        full = full.cpu().numpy()
+        hist, shift = full[:ncols], float(full[ncols:].max()) / 1024.0
+        new = rebalance_cuts(self.cuts, hist, min_cols=min_columns_for_shift(shift))
+        b.set_face_shift(shift)
+        b.set_next_columns(new[self.rank], new[self.rank + 1])
+        self.cuts = new

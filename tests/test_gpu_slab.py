@@ -299,3 +299,107 @@ def test_column_counts_describe_the_last_sort_after_the_cuts_moved(oracle):
     after = b.column_counts()
     assert np.array_equal(after, before)
     b.close()
+
+
+# ---- exchange issued by the library (overlapped slab step) ------------------------------------------------------------------
+
+def attach_chain(backends, rec_capacity=1 << 16):
+    for r, b in enumerate(backends):
+        b.attach_local(backends[r - 1] if r > 0 else None, backends[r + 1] if r < len(backends) - 1 else None,
+                       rec_capacity)
+
+
+@pytest.mark.parametrize("nslabs,rebalance", [(2, False), (3, True), (4, True)])
+def test_library_exchange_matches_single_context_bitwise(oracle, nslabs, rebalance):
+    """Slabs whose records the library moves itself (faces first, interior columns while the records travel; LOCAL
+    transport between contexts on one GPU), with moving cut planes: bit-identical to the single context per
+    particle id, intermediates of the last step included."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=16)
+    backends, cuts = make_slabs(p, pos, vel, ids, nslabs, oracle)
+    attach_chain(backends)
+    slab.halo_local_slabs(backends)
+    with capi.Simulation(p, n_max=ids.size) as single:
+        single.upload(pos, vel)
+        for s in range(12):
+            slab.step_local_slabs_overlapped(backends)
+            if rebalance and s % 2 == 1:
+                cuts = slab.rebalance_next_local_slabs(backends, cuts)
+            single.step(1)
+            assert sum(b.n for b in backends) >= ids.size  # own particles + the records received for the next step
+        rp, rv = single.download()
+        rrho, rf, rnc, _ = single.download_debug()
+    rho = np.empty(ids.size, np.float32); f = np.empty((ids.size, 3), np.float32); nc = np.empty(ids.size, np.int32)
+    gp = np.empty((ids.size, 3), np.float32); gv = np.empty((ids.size, 3), np.float32)
+    seen = np.zeros(ids.size, np.int32)
+    for b in backends:
+        bp, bv, bid = b.download()           # own particles first, then the records received for the next step
+        brho, bf, bnc, _ = b.download_debug()
+        k = brho.shape[0]                    # = particles this slab advanced in the last step
+        own = bid[:k]
+        gp[own], gv[own], rho[own], f[own], nc[own] = bp[:k], bv[:k], brho, bf, bnc
+        seen[own] += 1
+    assert np.all(seen == 1), "every particle is advanced by exactly one slab"
+    assert bits_equal(gp, rp) and bits_equal(gv, rv)
+    assert bits_equal(rho, rrho) and bits_equal(f, rf) and np.array_equal(nc, rnc)
+    assert all(b.lost() == 0 and b.missed() == 0 for b in backends)
+    for b in backends:
+        b.close()
+
+
+def test_library_exchange_dam_break_with_fast_front(oracle):
+    """250k-particle dam break on 4 slabs, 40 steps, rebalanced every other step: the collapse front crosses 2-4
+    columns per step, so the face ranges follow the measured column shift; compared with the single context."""
+    side = 63
+    pos, vel, p = scenes.dam_break(side)
+    ids = np.arange(pos.shape[0], dtype=np.int32)
+    p.flags = SPH_FLAG_SURFACE_TENSION
+    backends, cuts = make_slabs(p, pos, vel, ids, 4, oracle, n_max=ids.size)
+    attach_chain(backends, rec_capacity=1 << 17)
+    slab.halo_local_slabs(backends)
+    with capi.Simulation(p, n_max=ids.size) as single:
+        single.upload(pos, vel)
+        for s in range(40):
+            slab.step_local_slabs_overlapped(backends)
+            if s % 2 == 1:
+                cuts = slab.rebalance_next_local_slabs(backends, cuts)
+        single.step(40)
+        rp, rv = single.download()
+    gp = np.empty_like(rp); gv = np.empty_like(rv); seen = np.zeros(ids.size, np.int32)
+    loads = []
+    for b in backends:
+        bp, bv, bid = b.download()
+        lo, hi, _ = b.columns()
+        cols = oracle.cell_ids(p, bp) // (capi.global_cells(p) ** 2)
+        own = (cols >= lo) & (cols < hi)     # what this slab will advance next; the rest are its halo records
+        gp[bid[own]], gv[bid[own]] = bp[own], bv[own]
+        seen[bid[own]] += 1
+        loads.append(int(own.sum()))
+    assert np.all(seen == 1)
+    assert bits_equal(gp, rp) and bits_equal(gv, rv)
+    assert all(b.lost() == 0 and b.missed() == 0 for b in backends)
+    assert max(loads) < 1.6 * ids.size / 4, f"rebalancing left the slabs unbalanced: {loads}"
+    for b in backends:
+        b.close()
+
+
+def test_rccl_transport_single_rank(oracle):
+    """The RCCL transport end to end as far as one GPU allows: librccl loaded at run time, a one-rank communicator
+    created from sph_comm_unique_id, and the overlapped step driven through it (no neighbours to talk to): same
+    bits as the plain context."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=10)
+    gn = capi.global_cells(p)
+    b = capi.SlabSimulation(p, n_max=ids.size, col_lo=0, col_hi=gn)
+    b.upload(pos, vel, ids)
+    b.attach_rccl(capi.comm_unique_id(), 0, 1, rec_capacity=4096)
+    b.halo_begin(); b.halo_end()
+    for _ in range(3):
+        b.step_begin(); b.step_end()
+    with capi.Simulation(p, n_max=ids.size) as single:
+        single.upload(pos, vel)
+        single.step(3)
+        rp, rv = single.download()
+    got = by_id(*b.download())
+    assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
+    b.close()
