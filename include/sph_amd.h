@@ -206,6 +206,17 @@ int sph_update_particles_noalloc(const sph_params* params, float* d_particles, f
 int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos_aos,
                           float* vel_aos, int n);
 
+/*
+ * Scene generation in HBM, for fields too large to build on the host and push over PCIe (counterpart of
+ * initParticles' fill, compute.cpp:108-117, which draws its block from glibc rand()): the x-planes [x_lo, x_hi) of
+ * an nx*ny*nz simple-cubic lattice of the given spacing, every coordinate jittered by +-jitter*spacing with a
+ * counter-based generator keyed by (particle index, axis, seed); zero velocities; particle (i,j,k) gets id
+ * (i*ny + j)*nz + k.  Any context generates any planes of the same field identically (slabs generate their own).
+ * A plain context takes the whole lattice (x_lo = 0, x_hi = nx).  origin NULL = (0,0,0).  Asynchronous.
+ */
+int sph_fill_lattice(sph_context* ctx, int nx, int ny, int nz, int x_lo, int x_hi, double spacing, double jitter,
+                     uint64_t seed, const double origin[3]);
+
 /* ---- slab decomposition (one context per GPU / per process rank) -----------------------------
  *
  * The reference is a single shared-memory process (OpenMP only); it has no counterpart of this

@@ -41,6 +41,8 @@ _SIGNATURES = [
     ("sph_reset_timings", C.c_int, [_CTX]),
     ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
     ("sph_update_particles_noalloc", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("sph_fill_lattice", C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64,
+                                   C.c_void_p]),
     ("sph_fill_random_block", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     # slab decomposition
     ("sph_global_cells", C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -127,6 +129,14 @@ def _f32(a):
     return a
 
 
+def _fill_lattice(sim, nx, ny, nz, x_range=None, spacing=None, jitter=0.1, seed=12345, origin=None):
+    from .scenes import REST_SPACING
+    lo, hi = (0, nx) if x_range is None else x_range
+    o = (C.c_double * 3)(*origin) if origin is not None else None
+    _check(sim.lib.sph_fill_lattice(sim._ctx, int(nx), int(ny), int(nz), int(lo), int(hi),
+                                    float(REST_SPACING if spacing is None else spacing), float(jitter), int(seed), o))
+
+
 class Simulation:
     """One GPU context: mirrors the reference's initParticles / updateParticles life cycle
     (reference compute/compute.h:4-6) with the state resident in HBM between steps."""
@@ -178,6 +188,10 @@ class Simulation:
         n = pos.size // 3
         assert vel.size == pos.size
         _check(self.lib.sph_upload(self._ctx, pos.ctypes.data, vel.ctypes.data, n))
+
+    def fill_lattice(self, nx, ny, nz, **kw):
+        """Generate scenes.jittered_lattice(nx, ny, nz, ...) directly in HBM (same particles, bit for bit)."""
+        _fill_lattice(self, nx, ny, nz, None, **kw)
 
     def upload_device(self, d_pos_ptr, d_vel_ptr, n, producer_stream=None):
         """producer_stream: the stream that wrote the buffers (a hipStream_t as int); the context waits for it."""
@@ -299,6 +313,10 @@ class SlabSimulation:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         _check(self.lib.sph_slab_upload(self._ctx, pos.ctypes.data, vel.ctypes.data, ids.ctypes.data, ids.size))
 
+    def fill_lattice(self, nx, ny, nz, x_range, **kw):
+        """Generate the x-planes x_range of scenes.jittered_lattice(nx, ny, nz, ...) directly in HBM, global ids."""
+        _fill_lattice(self, nx, ny, nz, x_range, **kw)
+
     def download(self):
         cap = self.n_max
         pos = np.empty((cap, 3), np.float32)
@@ -319,6 +337,14 @@ class SlabSimulation:
                                                 cell.ctypes.data, cap))
         n = int(self.lib.sph_slab_last_own(self._ctx))  # the particles the last step advanced
         return rho[:n], f[:n], nc[:n], cell[:n]
+
+    def last_own(self):
+        """Particles the last step advanced (the first ones download() returns)."""
+        return int(self.lib.sph_slab_last_own(self._ctx))
+
+    def set_params(self, params):
+        _check(self.lib.sph_set_params(self._ctx, C.byref(params)))
+        self.params = params.copy()
 
     def lost(self):
         v = C.c_int64()

@@ -1441,6 +1441,30 @@ int sph_update_particles_noalloc(const sph_params* params, float* d_particles, f
   return SPH_OK;
 }
 
+int sph_fill_lattice(sph_context* c, int nx, int ny, int nz, int x_lo, int x_hi, double spacing, double jitter,
+                     uint64_t seed, const double origin[3]) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (nx < 1 || ny < 1 || nz < 1 || x_lo < 0 || x_hi > nx || x_hi < x_lo || !(spacing > 0.0) || !(jitter >= 0.0))
+    return fail(SPH_ERR_INVALID, "bad lattice %d x %d x %d, planes [%d, %d)", nx, ny, nz, x_lo, x_hi);
+  if ((long long)nx * ny * nz > 0x7fffffffLL) return fail(SPH_ERR_CAPACITY, "particle ids are 32-bit");
+  if (!c->slab && (x_lo != 0 || x_hi != nx))
+    return fail(SPH_ERR_INVALID, "a plain context numbers its particles from 0: it takes the whole lattice");
+  const long long n = (long long)(x_hi - x_lo) * ny * nz;
+  if (n > c->n_max) return fail(SPH_ERR_CAPACITY, "%lld particles exceed n_max = %d", n, c->n_max);
+  HIP_TRY(hipSetDevice(c->device));
+  const double zero[3] = {0.0, 0.0, 0.0};
+  launch_fill_lattice(c->stream, c->cur, (long long)x_lo * ny * nz, (int)n, ny, nz, spacing, jitter, seed,
+                      origin ? origin : zero);
+  HIP_TRY(hipGetLastError());
+  c->n = (int)n;
+  c->n_pending = false;
+  c->uploaded = true;
+  c->stepped = false;
+  c->pre_valid = false;
+  c->halo_current = false;
+  return SPH_OK;
+}
+
 int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos, float* vel, int n) {
   if (!params || !pos || !vel || n < 0) return fail(SPH_ERR_INVALID, "bad argument");
   // 64-bit LCG (Knuth MMIX constants); the top 24 bits give a uniform fp32 in [0,1].

@@ -130,6 +130,8 @@ void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int
 void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out);
 void launch_split_aos_ids(hipStream_t s, const float* pos, const float* vel, const int32_t* ids, int n, State st);
 void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* vel, int32_t* ids);
+void launch_fill_lattice(hipStream_t s, const State& st, long long first, int n, int ny, int nz, double spacing,
+                         double jitter, unsigned long long seed, const double origin[3]);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
                        const ParticleRec* rec_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,

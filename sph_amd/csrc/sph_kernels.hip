@@ -426,6 +426,45 @@ __global__ void k_join_debug(DevParams P, const int32_t* __restrict__ start, int
   if (cell) cell[o] = cell_s[s];
 }
 
+// ---- scene generation on the device -----------------------------------------------------------------------------------
+// Jittered simple-cubic lattice, the counterpart of initParticles' fill (compute.cpp:108-117) for fields too large to
+// generate on the host: particle (i, j, k) has index idx = (i*ny + j)*nz + k and sits at
+// origin + (i+0.5, j+0.5, k+0.5)*spacing + (2u-1)*jitter*spacing, u = uniform [0,1) from a counter-based generator
+// keyed by (idx, axis, seed) - two rounds of the splitmix64 finaliser - so any context can generate any x-planes of
+// a field and get the same particles.  Evaluated in double, left to right, rounded once to float.
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void k_fill_lattice(State st, long long first, int n, int ny, int nz, double spacing, double jitter,
+                               unsigned long long seed, double ox, double oy, double oz) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long idx = first + t;
+  const long long k = idx % nz, j = (idx / nz) % ny, i = idx / ((long long)ny * nz);
+  const double ijk[3] = {(double)i, (double)j, (double)k};
+  const double o[3] = {ox, oy, oz};
+  float p[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const unsigned long long key = (unsigned long long)idx * 3ull + (unsigned long long)a + seed * 0x100000001B3ull;
+    const unsigned long long bits = splitmix64(splitmix64(key));
+    const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+    const double jit = u * 2.0 - 1.0;
+    p[a] = (float)(o[a] + (ijk[a] + 0.5) * spacing + jit * (jitter * spacing));
+  }
+  st.x[t] = p[0];
+  st.y[t] = p[1];
+  st.z[t] = p[2];
+  st.vx[t] = 0.0f;  // compute.cpp:114-116
+  st.vy[t] = 0.0f;
+  st.vz[t] = 0.0f;
+  st.id[t] = (int32_t)idx;
+}
+
 // Particles per local x-column, from the cell start table of the last sort.
 __global__ void k_column_counts(const int32_t* __restrict__ start, int nx, int cpc, int32_t* __restrict__ out) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,6 +557,13 @@ void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, 
   if (n_own <= 0) return;
   hipLaunchKernelGGL(k_join_debug, dim3(div_up(n_own, kBlock)), dim3(kBlock), 0, s, P, start, n_own, n_stride,
                      rec_s, force_o, ncount_s, cell_s, rho, force, ncount, cell);
+}
+
+void launch_fill_lattice(hipStream_t s, const State& st, long long first, int n, int ny, int nz, double spacing,
+                         double jitter, unsigned long long seed, const double origin[3]) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_lattice, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, st, first, n, ny, nz, spacing, jitter,
+                     seed, origin[0], origin[1], origin[2]);
 }
 
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out) {

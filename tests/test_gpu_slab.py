@@ -403,3 +403,46 @@ def test_rccl_transport_single_rank(oracle):
     got = by_id(*b.download())
     assert bits_equal(got[0], rp) and bits_equal(got[1], rv)
     b.close()
+
+
+# ---- the 8-GPU configurations, on the one GPU there is ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("scene,side", [("dam_break", 400), ("sloshing", 640)])
+def test_eight_slab_configurations_on_one_gpu(scene, side):
+    """The 64M-particle dam break and the 256M-particle sloshing tank (the configurations quoted on 8 GPUs) as 8 slab
+    contexts on one MI355X, records moved by the library, cut planes rebalanced every other step: every particle
+    advanced by exactly one slab at every step, none lost or missed, finite and inside the tank, worst slab within
+    1.2x of the mean."""
+    from sph_amd import slab_local
+    r = slab_local.run(scene, side, 8, steps=12, rebalance_every=2, check=True)
+    assert sum(r["own_particles"]) == side ** 3
+    assert r["lost"] == 0 and r["missed"] == 0
+    assert r["finite"] and r["min_coordinate"] >= 0.0 and r["max_coordinate"] <= np.float32(r["tank_size"])
+    assert r["worst_imbalance"] <= 1.2, r
+    print(r)
+
+
+def test_eight_slabs_match_single_context_at_8m():
+    """8 slabs against one context at 8M particles (200^3 dam break), 6 steps with moving cut planes: bit-identical
+    positions and velocities per particle id."""
+    from sph_amd import slab_local
+    side = 200
+    p, backends, cuts = slab_local.build("dam_break", side, 8)
+    slab.halo_local_slabs(backends)
+    with capi.Simulation(p, n_max=side ** 3) as single:
+        single.fill_lattice(side, side, side)
+        for s in range(6):
+            slab.step_local_slabs_overlapped(backends)
+            if s % 2 == 1:
+                cuts = slab.rebalance_next_local_slabs(backends, cuts)
+        single.step(6)
+        rp, rv = single.download()
+    seen = np.zeros(side ** 3, np.int8)
+    for b in backends:
+        bp, bv, bid = b.download()
+        k = b.last_own()
+        own = bid[:k]
+        seen[own] += 1
+        assert bits_equal(bp[:k], rp[own]) and bits_equal(bv[:k], rv[own])
+        b.close()
+    assert np.all(seen == 1)
