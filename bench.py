@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rest-figure", action="store_true", help="skip the rest-density extra (steps 5-25)")
     ap.add_argument("--rebalance-every", type=int, default=2, help="multi-GPU: steps between cut-plane moves")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the multi-GPU code path even with one rank (rehearsal of the slab driver on a 1-GPU box)")
     ap.add_argument("--transport", default="library", choices=["library", "torch"],
                     help="multi-GPU: halo exchange issued by the library (RCCL from C++) or by torch.distributed")
     return ap.parse_args()
@@ -217,7 +219,7 @@ def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_slab:
         from sph_amd import slab_bench
         return slab_bench.main(args)
 

@@ -80,10 +80,21 @@ void dam_break_block(int side, uint64_t seed, sph_params* p, std::vector<float>*
   }
 }
 
+// Sloshing scene: the reference's gravity vector is a mutable global (compute.cpp:12) that a driver may turn between
+// steps; here it swings about the z axis by +-15 degrees with a period of 400 steps.
+void sloshing_gravity(uint32_t step, float g[3]) {
+  const double ang = 15.0 * M_PI / 180.0 * std::sin(2.0 * M_PI * (double)step / 400.0);
+  g[0] = (float)(10.0 * std::sin(ang));
+  g[1] = (float)(-10.0 * std::cos(ang));
+  g[2] = 0.0f;
+}
+
 void usage() {
   std::puts(
-      "sph_headless [--n N] [--scene random|dam] [--side S] [--steps K] [--seed X] [--mode shim|resident]\n"
-      "             [--dump-every D] [--out PREFIX] [--resume FILE] [--exact]");
+      "sph_headless [--n N] [--scene random|dam|slosh] [--side S] [--steps K] [--seed X] [--mode shim|resident]\n"
+      "             [--dump-every D] [--out PREFIX] [--resume FILE] [--exact]\n"
+      "  random  the reference's scene (main.cpp:8, compute.cpp:108-117); dam  side^3 block in the corner of a tank twice\n"
+      "  as wide; slosh  the same block under a gravity vector that swings +-15 degrees about z (period 400 steps)");
 }
 
 }  // namespace
@@ -118,7 +129,7 @@ int main(int argc, char** argv) {
   uint32_t step0 = 0;
   if (!resume.empty()) {
     if (!read_dump(resume, &p, &step0, &pos, &vel)) { std::fprintf(stderr, "cannot read %s\n", resume.c_str()); return 1; }
-  } else if (scene == "dam") {
+  } else if (scene == "dam" || scene == "slosh") {
     dam_break_block(side, seed, &p, &pos, &vel);
   } else {
     // the reference's own scene, through the drop-in initParticles (main.cpp:27)
@@ -145,6 +156,11 @@ int main(int argc, char** argv) {
   }
   auto t0 = std::chrono::steady_clock::now();
   for (int s = 1; s <= steps; s++) {
+    if (scene == "slosh") {  // gravity of step number step0 + s - 1, counted from the start of the run (resumes continue)
+      sloshing_gravity(step0 + (uint32_t)s - 1u, p.gravity);
+      a_gravity[0] = p.gravity[0]; a_gravity[1] = p.gravity[1]; a_gravity[2] = p.gravity[2];  // what updateParticles reads
+      if (ctx && sph_set_params(ctx, &p) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
+    }
     if (ctx) {
       if (sph_step(ctx, 1) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
     } else {

@@ -25,11 +25,14 @@ def main(args):
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} ranks (launch with torch.distributed.run); "
                          f"got WORLD_SIZE={world}")
     shared_gpu = os.environ.get("SPH_BENCH_SHARED_GPU") == "1"  # rehearsal: all ranks on GPU 0, gloo transport
+    library = getattr(args, "transport", "library") == "library" and not shared_gpu
     dev_index = 0 if shared_gpu else local
     if shared_gpu:
         torch.set_num_threads(1)  # host-staged records: many ranks' intra-op thread pools would fight for the cores
     torch.cuda.set_device(dev_index)
-    dist.init_process_group("gloo" if shared_gpu else "nccl", rank=rank, world_size=world)
+    # library transport: the records travel over RCCL issued from C++; torch.distributed (gloo, host) only hands out the
+    # communicator id and reduces the column histogram when cut planes move.  torch transport: everything through it.
+    dist.init_process_group("gloo" if (shared_gpu or library) else "nccl", rank=rank, world_size=world)
     device = torch.device("cuda", dev_index)
 
     side = int(round(args.side * world ** (1.0 / 3.0)))
@@ -44,38 +47,48 @@ def main(args):
     hist = np.bincount(plane_col, minlength=gn) * side * side
     cuts = slab.partition_columns(hist, world)
     # lattice planes whose (unjittered) column falls into this rank's slab; jitter may move a particle
-    # across the face, which the first pack/exchange handles like any other migrant
+    # across the face, which the first exchange handles like any other migrant
     mine = np.nonzero((plane_col >= cuts[rank]) & (plane_col < cuts[rank + 1]))[0]
     i0, i1 = (int(mine[0]), int(mine[-1]) + 1) if mine.size else (0, 0)
-    pos, vel, ids = scenes.dam_break_planes(side, (i0, i1))
     n_max = int(2.0 * n_total / world) + 4 * side * side * 8
+    rec_capacity = max(1 << 16, 48 * side * side)
     sim = capi.SlabSimulation(p, n_max=n_max, col_lo=cuts[rank], col_hi=cuts[rank + 1], cols_capacity=gn,
-                              device=dev_index, rec_capacity=max(1 << 16, 48 * side * side))
-    stream = torch.cuda.Stream(device=device)
-    sim.use_stream(stream.cuda_stream)   # kernels and RCCL transfers are ordered on one stream
-    sim.upload(pos, vel, ids)
-    runner = slab.SlabRunner(sim, slab.DistExchange(rank, world, device=device), rank, world, cuts,
-                             rebalance_every=args.rebalance_every)
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            runner.step()
-        sim.sync()
-        sim.enable_timing(not args.no_events)
-        sim.reset_timings()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            runner.step()
-        sim.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        dt = time.perf_counter() - t0
+                              device=dev_index, rec_capacity=1024 if library else rec_capacity)
+    sim.fill_lattice(side, side, side, (i0, i1))  # every rank generates its own planes in HBM
+    preroll = getattr(args, "preroll", 0)
+    if library:
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        sim.attach_rccl(uid[0], rank, world, rec_capacity)
+        runner = slab.LibraryRunner(sim, rank, world, cuts, rebalance_every=args.rebalance_every)
+        runner.prime()
+    else:
+        stream = torch.cuda.Stream(device=device)
+        sim.use_stream(stream.cuda_stream)   # kernels and RCCL transfers are ordered on one stream
+        runner = slab.SlabRunner(sim, slab.DistExchange(rank, world, device=device), rank, world, cuts,
+                                 rebalance_every=args.rebalance_every)
+        torch.cuda.set_stream(stream)
+    for _ in range(preroll + args.warmup):
+        runner.step()
+    sim.sync()
+    sim.enable_timing(not args.no_events)
+    sim.reset_timings()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    sim.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
     tm = sim.timings()
-    stats = torch.tensor([dt, float(sim.n), float(sim.lost()), tm["force_ms"], tm["density_ms"],
-                          float(runner.exchange.bytes_sent)], dtype=torch.float64)
+    n_own = sim.last_own() if library else sim.n
+    sent = 0.0 if library else float(runner.exchange.bytes_sent)
+    stats = torch.tensor([dt, float(n_own), float(sim.lost() + (sim.missed() if library else 0)), tm["force_ms"],
+                          tm["search_ms"] + tm["density_ms"], sent], dtype=torch.float64)
     gathered = [torch.zeros_like(stats) for _ in range(world)] if rank == 0 else None
-    if shared_gpu:
+    if shared_gpu or library:
         dist.gather(stats, gathered, dst=0)
     else:
         g = [torch.zeros_like(stats, device=device) for _ in range(world)] if rank == 0 else None
@@ -102,7 +115,10 @@ def main(args):
             "data": "synthetic",
             "config": {"workload": f"dam_break_{side}^3", "particles": n_total, "particles_per_gpu": n_total // world,
                        "tank_size": float(p.tank_size), "h": float(p.h), "surface_tension": True,
-                       "parallelism": f"{world} slabs along x, 2-column halo, RCCL send/recv",
+                       "parallelism": (f"{world} slabs along x, 2-column halo, " +
+                                       ("RCCL send/recv issued by the library, overlapped with the interior columns"
+                                        if library else "torch.distributed send/recv")),
+                       "phase": {"preroll_steps": preroll, "timed_steps": [preroll + args.warmup, preroll + args.warmup + args.steps]},
                        "final_cuts": [int(c) for c in runner.cuts],
                        "particles_per_rank": [int(v) for v in g[:, 1]]},
         }
@@ -115,7 +131,8 @@ def main(args):
             out["roofline"] = {"bound": "hbm", "kernel": "k_force", "achieved": achieved, "peak": 8000.0,
                                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                "bytes_per_particle": 52, "avg_launch_ms": force_ms, "rank": k}
-        out["halo_bytes_per_step_per_rank"] = float(g[:, 5].mean() / args.steps)
+        if not library:
+            out["halo_bytes_per_step_per_rank"] = float(g[:, 5].mean() / args.steps)
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

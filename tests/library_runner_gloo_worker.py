@@ -1,0 +1,73 @@
+"""Worker of tests/test_slab_cpu.py::test_library_runner_rebalances_consistently_over_gloo (one process per rank).
+
+LibraryRunner keeps torch.distributed off the data path: it only all-reduces the column histogram and the largest
+column shift when the cut planes move.  Here two ranks run it over gloo around a stand-in for the slab context (the
+real one needs a GPU) that records what the runner asks of it; both ranks must arrive at the same cuts, move each
+face by at most one column per call, and pass the largest shift of ALL ranks to every context."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sph_amd import slab  # noqa: E402
+
+
+class StandIn:
+    def __init__(self, hist, cuts, rank, shift):
+        self.hist, self.cuts, self.rank, self.shift = hist, list(cuts), rank, shift
+        self.calls, self.face_shift, self.next = [], None, None
+
+    def step_begin(self):
+        self.calls.append("begin")
+
+    def step_end(self):
+        self.calls.append("end")
+        if self.next is not None:  # new faces take effect with the step after the one whose records they shaped
+            self.cuts[self.rank], self.cuts[self.rank + 1] = self.next
+            self.next = None
+
+    def load_info(self):
+        lo, hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+        return self.hist[lo:hi].astype(np.int32), self.shift
+
+    def set_face_shift(self, v):
+        self.face_shift = v
+
+    def set_next_columns(self, lo, hi):
+        self.next = (lo, hi)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncols = 40
+    hist = np.zeros(ncols, np.int64)
+    hist[2:14] = 1000  # all the particles sit in the left third: the cut must travel left
+    cuts = [0, 30, ncols]
+    b = StandIn(hist, cuts, rank, shift=0.5 + 2.0 * rank)
+    runner = slab.LibraryRunner(b, rank, world, cuts, rebalance_every=1)
+    seen = [list(cuts)]
+    for _ in range(12):
+        runner.step()
+        b.cuts = list(runner.cuts) if b.next is None else b.cuts
+        seen.append(list(runner.cuts))
+    moves = [abs(a[1] - c[1]) for a, c in zip(seen, seen[1:])]
+    assert max(moves) <= 1, moves
+    assert seen[-1][1] < 30 - 8, seen[-1]
+    assert abs(b.face_shift - 2.5) < 1e-2, b.face_shift  # the larger of the two ranks' shifts, on both ranks
+    assert b.calls[:2] == ["begin", "end"]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, seen)
+    assert gathered[0] == gathered[1], "ranks disagree about the cut planes"
+    if rank == 0:
+        print("CONSISTENT", seen[-1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

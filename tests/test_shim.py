@@ -137,3 +137,29 @@ def test_headless_driver_modes_and_resume(tmp_path, oracle):
     run("--resume", "py.sphd", "--steps", "3", "--mode", "resident", "--exact", "--out", "py")
     _, _, ppos, _ = dumpio.read_dump(tmp_path / "py_final.sphd")
     assert bits_equal(ppos, pos6)
+
+
+@pytest.mark.gpu
+def test_headless_sloshing_scene(tmp_path, oracle):
+    """--scene slosh turns the gravity vector every step (the reference's mutable a_gravity, compute.cpp:12): resident
+    mode (sph_set_params) and shim mode (the a_gravity global) agree with each other and with the oracle bit for bit."""
+    from sph_amd import scenes
+
+    def run(*args):
+        r = subprocess.run([HEADLESS, *args], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+
+    run("--scene", "slosh", "--side", "11", "--steps", "5", "--mode", "resident", "--exact", "--dump-every", "1", "--out", "res")
+    run("--scene", "slosh", "--side", "11", "--steps", "5", "--mode", "shim", "--exact", "--out", "shim")
+    p, s1, pos1, vel1 = dumpio.read_dump(tmp_path / "res_000001.sphd")
+    pf, s5, pos5, vel5 = dumpio.read_dump(tmp_path / "res_final.sphd")
+    _, _, spos5, svel5 = dumpio.read_dump(tmp_path / "shim_final.sphd")
+    assert (s1, s5) == (1, 5) and bits_equal(pos5, spos5) and bits_equal(vel5, svel5)
+    po, vo = pos1.copy(), vel1.copy()
+    for step in range(1, 5):  # steps 2..5 of the run use the gravity of step indices 1..4
+        q = p.copy()
+        g = scenes.sloshing_gravity(step)
+        q.gravity[0], q.gravity[1], q.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+        oracle.step_allpairs(q, po, vo)
+    assert bits_equal(po, pos5) and bits_equal(vo, vel5)
+    assert abs(pf.gravity[0]) > 0.0  # the dump records the turned vector

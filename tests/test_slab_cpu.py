@@ -179,3 +179,15 @@ def test_gloo_two_ranks_match_single_domain(tmp_path, sizing):
     for r, pr in enumerate(procs):
         assert pr.returncode == 0, f"rank {r} failed:\n{outs[r]}"
     assert "BITWISE_MATCH" in outs[0], outs[0]
+
+
+def test_library_runner_rebalances_consistently_over_gloo():
+    script = os.path.join(ROOT, "tests", "library_runner_gloo_worker.py")
+    port = 31500 + (os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [pr.communicate(timeout=240)[0] for pr in procs]
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r} failed:\n{outs[r]}"
+    assert "CONSISTENT" in outs[0], outs[0]
