@@ -41,6 +41,8 @@ sph_params params_from_globals() {
   p.h = h;
   if (const char* e = std::getenv("SPH_AMD_EXACT"))
     if (e[0] == '1') p.flags |= SPH_FLAG_EXACT_ORDER;  // bit-identical to the reference, slower
+  if (const char* e = std::getenv("SPH_AMD_REFERENCE_ARITH"))
+    if (e[0] == '1') p.flags |= SPH_FLAG_REFERENCE_ARITH;  // the reference's term arithmetic, stencil order
   return p;
 }
 
