@@ -63,15 +63,30 @@ __global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const Part
 }
 
 // ---- hash + histogram ---------------------------------------------------------------------------------
-// The state arrives in the previous step's cell order, so neighbouring lanes mostly hash to the same cell: a run
-// of equal cells inside a wave takes ONE atomic (by its first lane, for the whole run) instead of one per lane.
-// The ranks are provisional either way; k_reorder replaces them by the rank of the id within the cell.
+// Global atomics are the expensive part of a histogram on this chip (they are served at the memory side of the
+// fabric), so each WAVE first counts its 64 particles per cell in a small LDS table of its own (open addressing, LDS
+// atomics; a run of equal cells in consecutive lanes is entered once, by its first lane) and then issues ONE global
+// atomic per distinct cell.  The state arrives in the previous step's cell order, so a wave meets few distinct cells,
+// however much the order has been stirred since.  Waves never wait for one another: no block barrier.  The ranks are
+// provisional either way; k_reorder replaces them by the rank of the id within the cell.
+constexpr int kWaveSlots = 128;  // 64 keys at most: load factor <= 1/2
+__device__ inline void wave_lds_fence() {
+  // LDS operations of one wave execute in program order; this only stops the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 __global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, int32_t* __restrict__ cell_of,
                                                  int32_t* __restrict__ rank_of, int32_t* __restrict__ count) {
+  __shared__ int key_all[kBlock / 64][kWaveSlots];
+  __shared__ int cnt_all[kBlock / 64][kWaveSlots];  // particles of the wave in that cell; afterwards the base rank
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  int* key = key_all[threadIdx.x >> 6];
+  int* cnt = cnt_all[threadIdx.x >> 6];
+  key[lane] = -1; key[lane + 64] = -1;
+  cnt[lane] = 0; cnt[lane + 64] = 0;
   const bool valid = i < n;
-  int c = -1 - lane;  // lanes without a particle: distinct keys, no atomics
+  int c = -1 - lane;  // lanes without a particle: distinct keys, never entered
   if (valid) {
     // A particle whose x-column lies outside this context's local grid (possible only in slab mode) goes to
     // the trash cell appended after the last real cell: it sorts behind everything and no pass visits it.
@@ -87,12 +102,29 @@ __global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, i
   const int head_lane = 63 - __clzll((long long)(heads & upto));
   const unsigned long long above = heads & ~upto;
   const int next_head = above ? __ffsll((long long)above) - 1 : 64;
-  int base = 0;
-  if (head && valid) base = atomicAdd(&count[c], next_head - head_lane);
-  base = __shfl(base, head_lane, 64);
+  wave_lds_fence();
+  int at = 0, local = 0;
+  if (head && valid) {
+    at = (int)(((uint32_t)c * 0x9E3779B1u) >> 25) & (kWaveSlots - 1);
+    for (;;) {  // at most 64 distinct keys in 128 slots: always terminates
+      const int old = atomicCAS(&key[at], -1, c);
+      if (old == -1 || old == c) break;
+      at = (at + 1) & (kWaveSlots - 1);
+    }
+    local = atomicAdd(&cnt[at], next_head - head_lane);
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int t = lane; t < kWaveSlots; t += 64) {
+    const int k = key[t];
+    if (k >= 0) cnt[t] = atomicAdd(&count[k], cnt[t]);
+  }
+  wave_lds_fence();
+  at = __shfl(at, head_lane, 64);
+  local = __shfl(local, head_lane, 64);
   if (valid) {
     cell_of[i] = c;
-    rank_of[i] = base + lane - head_lane;
+    rank_of[i] = cnt[at] + local + lane - head_lane;
   }
 }
 
@@ -221,36 +253,47 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ cou
 }
 
 // ---- counting sort ---------------------------------------------------------------------------------------
+// Provisional placement: particle i goes to the slot its arrival rank gives it inside its cell's range.  What lands
+// there is what the final pass needs in slot order: where the particle came from, its id and its cell (the cell of a
+// slot is final already: the final pass only permutes particles inside their cell's range).
 __global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
                           const int32_t* __restrict__ start, const int32_t* __restrict__ id_in,
-                          int32_t* __restrict__ src_of, int32_t* __restrict__ id_prov) {
+                          int32_t* __restrict__ src_of, int32_t* __restrict__ id_prov, int32_t* __restrict__ cell_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int slot = start[cell_of[i]] + rank_of[i];
+  const int c = cell_of[i];
+  const int slot = start[c] + rank_of[i];
   src_of[slot] = i;
   id_prov[slot] = id_in[i];
+  cell_s[slot] = c;
 }
 
 // Final slot = cell start + number of cell-mates with a smaller id: the in-cell order no longer depends
-// on the order in which the histogram atomics happened to be served.
-__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ cell_of,
-                          const int32_t* __restrict__ start, const int32_t* __restrict__ src_of,
-                          const int32_t* __restrict__ id_prov, int32_t* __restrict__ cell_s) {
+// on the order in which the histogram atomics happened to be served.  The lanes of a wave are consecutive slots,
+// hence mostly cell-mates that count over the same ids: those loads are one request per wave.
+__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ start,
+                          const int32_t* __restrict__ src_of, const int32_t* __restrict__ id_prov,
+                          const int32_t* __restrict__ cell_s) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  int i = src_of[s];
-  int c = cell_of[i];
-  int my = id_prov[s];
-  int b = start[c], e = start[c + 1];
-  int r = 0;
-  for (int t = b; t < e; t++) r += id_prov[t] < my;
-  int d = b + r;
+  const int i = src_of[s];
+  const int my = id_prov[s];
+  const int c = cell_s[s];
+  const int b = start[c], e = start[c + 1];
   const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
+  const float4 vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);
+  int r = 0;
+  int t = b;
+  for (; t + 4 <= e; t += 4) {  // four independent loads per trip
+    const int a0 = id_prov[t], a1 = id_prov[t + 1], a2 = id_prov[t + 2], a3 = id_prov[t + 3];
+    r += (a0 < my) + (a1 < my) + (a2 < my) + (a3 < my);
+  }
+  for (; t < e; t++) r += id_prov[t] < my;
+  const int d = b + r;
   out.pos[d] = pos;
-  out.rec[d].pos = pos;  // w receives 1/density (fast-arithmetic density pass)
-  out.rec[d].vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
+  out.rec[d].pos = pos;  // w receives 1/density
+  out.rec[d].vel = vel;  // w receives the density
   out.id[d] = my;
-  cell_s[d] = c;
 }
 
 // ---- slab decomposition: halo/migration records ---------------------------------------------------------------
@@ -497,9 +540,9 @@ void launch_scan(hipStream_t s, GridBuffers g) {
 void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, GridBuffers g) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, g.cell_of, g.rank_of, g.start,
-                     in.id, g.src_of, g.id_prov);
-  hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.cell_of, g.start,
-                     g.src_of, g.id_prov, g.cell_s);
+                     in.id, g.src_of, g.id_prov, g.cell_s);
+  hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.start, g.src_of, g.id_prov,
+                     g.cell_s);
 }
 
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, const int32_t* n_dev, int col_lo,
