@@ -217,6 +217,26 @@ int sph_fill_random_block(const sph_params* params, uint64_t seed, float* pos_ao
 int sph_fill_lattice(sph_context* ctx, int nx, int ny, int nz, int x_lo, int x_hi, double spacing, double jitter,
                      uint64_t seed, const double origin[3]);
 
+/* ---- viewer hand-off ------------------------------------------------------------------------------------------
+ * Counterpart of the reference's display(particles, numParticles) (render/render.cpp:240-260), which copies the
+ * positions to the GPU every frame and draws one sphere per particle.  Here the state is drawn where it lives (HBM)
+ * and only the finished picture leaves the device.  Camera and shading follow the reference: model matrix =
+ * translate(translation) * rotation(quat) with the trackball's quaternion layout (x, y, z, w) and its matrix
+ * (render/trackball.cpp:326-346), view matrix = identity, perspective(fov, width/height, z_near, z_far)
+ * (render.cpp:155-171), spheres of `radius` (render.cpp:187), light and material of vs_basic.glsl / fs_simple.glsl,
+ * white background (render.cpp:297).  Spheres are drawn as per-pixel impostors, not tessellated. */
+typedef struct sph_camera {
+  float translation[3]; /* modelTranslation = {0, 0, -1.5}   render.cpp:26  */
+  float quat[4];        /* curquat = identity {0, 0, 0, 1}   render.cpp:295 */
+  float fov_deg;        /* 45                                render.cpp:157 */
+  float z_near, z_far;  /* 0.01, 10                          render.cpp:155-156 */
+  float radius;         /* 0.0025                            render.cpp:187 */
+} sph_camera;
+int sph_camera_default(sph_camera* cam);
+/* Draw the context's particles into rgb (HOST buffer, 3 * width * height bytes, top row first, R G B).
+ * Synchronous.  width, height in [1, 16384]. */
+int sph_render_frame(sph_context* ctx, const sph_camera* cam, int width, int height, unsigned char* rgb);
+
 /* ---- slab decomposition (one context per GPU / per process rank) -----------------------------
  *
  * The reference is a single shared-memory process (OpenMP only); it has no counterpart of this

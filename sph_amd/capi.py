@@ -17,6 +17,14 @@ LIB_PATH = os.environ.get("SPH_AMD_LIB") or os.path.join(os.path.dirname(os.path
 # Every symbol include/sph_amd.h declares: (name, restype, argtypes)
 _P = C.POINTER(SphParams)
 _CTX = C.c_void_p
+
+
+class SphCamera(C.Structure):
+    """struct sph_camera of include/sph_amd.h (the reference's camera, render/render.cpp:26,155-157,187)."""
+    _fields_ = [("translation", C.c_float * 3), ("quat", C.c_float * 4), ("fov_deg", C.c_float),
+                ("z_near", C.c_float), ("z_far", C.c_float), ("radius", C.c_float)]
+
+
 _SIGNATURES = [
     ("sph_version", C.c_char_p, []),
     ("sph_last_error", C.c_char_p, []),
@@ -74,6 +82,8 @@ _SIGNATURES = [
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
     ("sph_stream_wait", C.c_int, [_CTX, C.c_void_p]),
+    ("sph_camera_default", C.c_int, [C.POINTER(SphCamera)]),
+    ("sph_render_frame", C.c_int, [_CTX, C.POINTER(SphCamera), C.c_int, C.c_int, C.c_void_p]),
 ]
 
 NOALLOC_MAX_PARTICLES = 32768  # SPH_NOALLOC_MAX_PARTICLES
@@ -127,6 +137,20 @@ def _check(rc):
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a
+
+
+def default_camera():
+    cam = SphCamera()
+    _check(load().sph_camera_default(C.byref(cam)))
+    return cam
+
+
+def _render(sim, width, height, camera=None):
+    """The context's particles drawn as shaded spheres: uint8 array [height, width, 3], top row first."""
+    cam = camera if camera is not None else default_camera()
+    img = np.empty((int(height), int(width), 3), dtype=np.uint8)
+    _check(sim.lib.sph_render_frame(sim._ctx, C.byref(cam), int(width), int(height), img.ctypes.data))
+    return img
 
 
 def _fill_lattice(sim, nx, ny, nz, x_range=None, spacing=None, jitter=0.1, seed=12345, origin=None):
@@ -192,6 +216,9 @@ class Simulation:
     def fill_lattice(self, nx, ny, nz, **kw):
         """Generate scenes.jittered_lattice(nx, ny, nz, ...) directly in HBM (same particles, bit for bit)."""
         _fill_lattice(self, nx, ny, nz, None, **kw)
+
+    def render(self, width, height, camera=None):
+        return _render(self, width, height, camera)
 
     def upload_device(self, d_pos_ptr, d_vel_ptr, n, producer_stream=None):
         """producer_stream: the stream that wrote the buffers (a hipStream_t as int); the context waits for it."""
@@ -337,6 +364,9 @@ class SlabSimulation:
                                                 cell.ctypes.data, cap))
         n = int(self.lib.sph_slab_last_own(self._ctx))  # the particles the last step advanced
         return rho[:n], f[:n], nc[:n], cell[:n]
+
+    def render(self, width, height, camera=None):
+        return _render(self, width, height, camera)
 
     def last_own(self):
         """Particles the last step advanced (the first ones download() returns)."""

@@ -98,6 +98,10 @@ struct sph_context {
   int next_lo = 0, next_hi = 0;            // faces the NEXT exchange packs for (set_next_columns)
   float face_shift = 4.0f;                 // columns a particle may cross per step: how wide the face ranges are
   int64_t missed = 0;
+  // frame rendering (viewer hand-off): depth-keyed frame buffer and the resolved picture, grown on demand
+  unsigned long long* frame_fb = nullptr;
+  unsigned char* frame_rgb = nullptr;
+  size_t frame_pixels = 0;
   bool timing = false;
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
@@ -508,6 +512,8 @@ int sph_destroy(sph_context* c) {
   if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
   if (c->rccl) rccl_comm_destroy(c->rccl);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
+  (void)hipFree(c->frame_fb);
+  (void)hipFree(c->frame_rgb);
   if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SPH_OK;
@@ -641,6 +647,67 @@ int sph_download_debug(sph_context* c, float* rho, float* force, int32_t* ncount
   if (force) HIP_TRY(hipMemcpyAsync(force, d_force, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (ncount) HIP_TRY(hipMemcpyAsync(ncount, d_ncount, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   if (cell) HIP_TRY(hipMemcpyAsync(cell, d_cell, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SPH_OK;
+}
+
+int sph_camera_default(sph_camera* cam) {
+  if (!cam) return fail(SPH_ERR_INVALID, "cam is NULL");
+  cam->translation[0] = 0.0f; cam->translation[1] = 0.0f; cam->translation[2] = -1.5f;  // render.cpp:26
+  cam->quat[0] = 0.0f; cam->quat[1] = 0.0f; cam->quat[2] = 0.0f; cam->quat[3] = 1.0f;     // trackball(q, 0, 0, 0, 0)
+  cam->fov_deg = 45.0f;   // render.cpp:157
+  cam->z_near = 0.01f;    // :155
+  cam->z_far = 10.0f;     // :156
+  cam->radius = 0.0025f;  // :187
+  return SPH_OK;
+}
+
+int sph_render_frame(sph_context* c, const sph_camera* cam, int width, int height, unsigned char* rgb) {
+  if (!c || !cam || !rgb) return fail(SPH_ERR_INVALID, "NULL argument");
+  if (width < 1 || height < 1 || width > 16384 || height > 16384)
+    return fail(SPH_ERR_INVALID, "frame size %d x %d outside [1, 16384]", width, height);
+  if (!c->uploaded) return fail(SPH_ERR_STATE, "sph_render_frame before upload");
+  if (!(cam->fov_deg > 0.0f && cam->fov_deg < 180.0f) || !(cam->z_near > 0.0f) || !(cam->z_far > cam->z_near) ||
+      !(cam->radius > 0.0f))
+    return fail(SPH_ERR_INVALID, "camera needs 0 < fov < 180, 0 < z_near < z_far, radius > 0");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resolve_n(c);
+  if (rc != SPH_OK) return rc;
+  const size_t pixels = (size_t)width * height;
+  if (pixels > c->frame_pixels) {
+    (void)hipFree(c->frame_fb);
+    (void)hipFree(c->frame_rgb);
+    c->frame_fb = nullptr;
+    c->frame_rgb = nullptr;
+    c->frame_pixels = 0;
+    HIP_TRY(hipMalloc((void**)&c->frame_fb, pixels * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->frame_rgb, pixels * 3));
+    c->frame_pixels = pixels;
+  }
+  RenderCamera rcam;
+  const float* q = cam->quat;
+  // build_rotmatrix(glm::mat4&, q) fills m[column][row] (render/trackball.cpp:326-346); M[row][column] below
+  rcam.m[0][0] = 1.0f - 2.0f * (q[1] * q[1] + q[2] * q[2]);
+  rcam.m[1][0] = 2.0f * (q[0] * q[1] - q[2] * q[3]);
+  rcam.m[2][0] = 2.0f * (q[2] * q[0] + q[1] * q[3]);
+  rcam.m[0][1] = 2.0f * (q[0] * q[1] + q[2] * q[3]);
+  rcam.m[1][1] = 1.0f - 2.0f * (q[2] * q[2] + q[0] * q[0]);
+  rcam.m[2][1] = 2.0f * (q[1] * q[2] - q[0] * q[3]);
+  rcam.m[0][2] = 2.0f * (q[2] * q[0] - q[1] * q[3]);
+  rcam.m[1][2] = 2.0f * (q[1] * q[2] + q[0] * q[3]);
+  rcam.m[2][2] = 1.0f - 2.0f * (q[1] * q[1] + q[0] * q[0]);
+  for (int a = 0; a < 3; a++) rcam.t[a] = cam->translation[a];
+  rcam.focal = 1.0f / tanf(0.5f * cam->fov_deg * 3.14159265358979323846f / 180.0f);
+  rcam.aspect = (float)width / (float)height;
+  rcam.z_near = cam->z_near;
+  rcam.z_far = cam->z_far;
+  rcam.radius = cam->radius;
+  {
+    Timed t(c, CAT_OTHER);
+    launch_render(c->stream, c->cur, c->n, rcam, width, height, c->frame_fb, c->frame_rgb);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb, c->frame_rgb, pixels * 3, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return SPH_OK;
 }

@@ -11,6 +11,9 @@
 //                    (host arrays valid after every call, as display() expects, render.cpp:240-253)
 //   --mode resident  state stays in HBM between steps (sph_upload once, sph_step, sph_download at dumps)
 //
+// --frames-every F writes a picture of the particles every F steps (PPM, drawn on the GPU from the resident state with
+// the reference's camera and shading: the counterpart of display(), render.cpp:240-260); resident mode only.
+//
 // Dump file: header {magic "SPHD", u32 version=1, u32 n, u32 step, sph_params (56 bytes)} = 72 bytes, then
 // float32 pos[3n], float32 vel[3n].  A dump is also a checkpoint: --resume FILE continues from it.
 #include <chrono>
@@ -89,10 +92,20 @@ void sloshing_gravity(uint32_t step, float g[3]) {
   g[2] = 0.0f;
 }
 
+bool write_ppm(const std::string& path, int w, int h, const std::vector<unsigned char>& rgb) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+  bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+  std::fclose(f);
+  return ok;
+}
+
 void usage() {
   std::puts(
       "sph_headless [--n N] [--scene random|dam|slosh] [--side S] [--steps K] [--seed X] [--mode shim|resident]\n"
       "             [--dump-every D] [--out PREFIX] [--resume FILE] [--exact]\n"
+      "             [--frames-every F] [--frame-size WxH] [--camera-z Z]   pictures PREFIX_NNNNNN.ppm (resident mode)\n"
       "  random  the reference's scene (main.cpp:8, compute.cpp:108-117); dam  side^3 block in the corner of a tank twice\n"
       "  as wide; slosh  the same block under a gravity vector that swings +-15 degrees about z (period 400 steps)");
 }
@@ -101,6 +114,8 @@ void usage() {
 
 int main(int argc, char** argv) {
   int n = 3000, steps = 100, side = 30, dump_every = 0;  // numParticles = 3000: main.cpp:8
+  int frames_every = 0, frame_w = 800, frame_h = 800;    // windowWidth/windowHeight = 800: render.cpp:19-20
+  float camera_z = -1.5f;                                // modelTranslation[2]: render.cpp:26
   uint64_t seed = 12345;
   bool exact = false;
   std::string scene = "random", mode = "resident", out = "sph_dump", resume;
@@ -120,6 +135,11 @@ int main(int argc, char** argv) {
     else if (a == "--out") out = val("--out");
     else if (a == "--resume") resume = val("--resume");
     else if (a == "--exact") exact = true;
+    else if (a == "--frames-every") frames_every = std::atoi(val("--frames-every"));
+    else if (a == "--camera-z") camera_z = (float)std::atof(val("--camera-z"));
+    else if (a == "--frame-size") {
+      if (std::sscanf(val("--frame-size"), "%dx%d", &frame_w, &frame_h) != 2) { usage(); return 2; }
+    }
     else { usage(); return a == "--help" ? 0 : 2; }
   }
 
@@ -154,6 +174,11 @@ int main(int argc, char** argv) {
       return 1;
     }
   }
+  if (frames_every > 0 && !ctx) { std::fprintf(stderr, "--frames-every needs --mode resident\n"); return 2; }
+  sph_camera cam;
+  sph_camera_default(&cam);
+  cam.translation[2] = camera_z;
+  std::vector<unsigned char> frame(frames_every > 0 ? (size_t)frame_w * frame_h * 3 : 0);
   auto t0 = std::chrono::steady_clock::now();
   for (int s = 1; s <= steps; s++) {
     if (scene == "slosh") {  // gravity of step number step0 + s - 1, counted from the start of the run (resumes continue)
@@ -165,6 +190,12 @@ int main(int argc, char** argv) {
       if (sph_step(ctx, 1) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
     } else {
       updateParticles(pos.data(), vel.data(), n);  // main.cpp:33
+    }
+    if (frames_every > 0 && s % frames_every == 0) {  // main.cpp:34, display() -> picture
+      if (sph_render_frame(ctx, &cam, frame_w, frame_h, frame.data()) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }
+      char name[512];
+      std::snprintf(name, sizeof name, "%s_%06u.ppm", out.c_str(), step0 + s);
+      if (!write_ppm(name, frame_w, frame_h, frame)) { std::fprintf(stderr, "cannot write %s\n", name); return 1; }
     }
     if (dump_every > 0 && s % dump_every == 0) {  // main.cpp:34, display() -> dump
       if (ctx && sph_download(ctx, pos.data(), vel.data()) != SPH_OK) { std::fprintf(stderr, "sph_amd: %s\n", sph_last_error()); return 1; }

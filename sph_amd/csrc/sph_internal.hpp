@@ -133,6 +133,15 @@ void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* v
 void launch_fill_lattice(hipStream_t s, const State& st, long long first, int n, int ny, int nz, double spacing,
                          double jitter, unsigned long long seed, const double origin[3]);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
+
+// Camera of a rendered frame in the form the splat kernel uses: view = m * position + t.
+struct RenderCamera {
+  float m[3][3], t[3];
+  float focal, aspect;  // 1 / tan(fov / 2), width / height
+  float z_near, z_far, radius;
+};
+void launch_render(hipStream_t s, const State& st, int n, const RenderCamera& cam, int width, int height,
+                   unsigned long long* fb, unsigned char* rgb);
 void launch_join_debug(hipStream_t s, const DevParams& P, const int32_t* start, int n_own, int n_stride,
                        const ParticleRec* rec_s, const float* force_o, const int32_t* ncount_s, const int32_t* cell_s,
                        float* rho, float* force, int32_t* ncount, int32_t* cell);

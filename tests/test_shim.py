@@ -163,3 +163,30 @@ def test_headless_sloshing_scene(tmp_path, oracle):
         oracle.step_allpairs(q, po, vo)
     assert bits_equal(po, pos5) and bits_equal(vo, vel5)
     assert abs(pf.gravity[0]) > 0.0  # the dump records the turned vector
+
+
+@pytest.mark.gpu
+def test_headless_writes_pictures(tmp_path):
+    """--frames-every: display()'s counterpart (render.cpp:240-260) writes a PPM drawn from the resident state; it is the
+    picture sph_render_frame gives for the dumped state."""
+    import numpy as np
+    from sph_amd import capi
+
+    r = subprocess.run([HEADLESS, "--scene", "dam", "--side", "12", "--steps", "4", "--mode", "resident", "--frames-every", "2",
+                        "--frame-size", "160x120", "--camera-z", "-0.8", "--dump-every", "4", "--out", "pic"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = (tmp_path / "pic_000004.ppm").read_bytes()
+    assert raw.startswith(b"P6\n160 120\n255\n") and (tmp_path / "pic_000002.ppm").exists()
+    img = np.frombuffer(raw[len(b"P6\n160 120\n255\n"):], dtype=np.uint8).reshape(120, 160, 3)
+    p, step, pos, vel = dumpio.read_dump(tmp_path / "pic_000004.sphd")
+    with capi.Simulation(p, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        cam = capi.default_camera()
+        cam.translation[2] = -0.8
+        again = sim.render(160, 120, cam)
+    assert (img != 255).any() and np.array_equal(img, again)
+    # shim mode keeps the state on the host: no pictures there
+    r = subprocess.run([HEADLESS, "--n", "100", "--steps", "1", "--mode", "shim", "--frames-every", "1"], capture_output=True,
+                       text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 2
