@@ -291,7 +291,10 @@ int sph_slab_download_debug(sph_context* ctx, float* rho, float* force, int32_t*
  * After the first call a context packs these records right behind every step (into buffers of its
  * own, counts travelling home with the particle count), so that the call between two steps is a
  * copy instead of a kernel and a second round trip; anything that changes the particle set or the
- * cut planes in between makes it pack on demand again. */
+ * cut planes in between makes it pack on demand again.  Those buffers are allocated by the first call and
+ * again only when `capacity` differs from the previous call's: keep it constant over a run.  The header
+ * count of this caller-driven protocol is the caller's to transport; sph_amd/slab.py sends it as an fp32
+ * word, exact to 2^24 records per face (the library-driven exchange below carries it as an integer). */
 int sph_slab_pack(sph_context* ctx, float* d_rec_left, float* d_rec_right, int capacity,
                   int* n_left, int* n_right);
 /* Add n_rec records from a DEVICE buffer to the particle set.  Read on the context's stream: see sph_stream_wait
