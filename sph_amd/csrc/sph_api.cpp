@@ -266,7 +266,7 @@ int layout_step_buffers(Source& src, sph_context* c, size_t n, size_t ncells) {
       (rc = dev_alloc(src, &s->vx, n)) || (rc = dev_alloc(src, &s->vy, n)) || (rc = dev_alloc(src, &s->vz, n)) ||
       (rc = dev_alloc(src, &s->id, n)))
     return rc;
-  if ((rc = dev_alloc(src, &c->sorted.pos, n + kSearchOverread)) || (rc = dev_alloc(src, &c->sorted.rec, n)) ||
+  if ((rc = dev_alloc(src, &c->sorted.pos3, 3 * (n + kSearchOverread))) || (rc = dev_alloc(src, &c->sorted.rec, n)) ||
       (rc = dev_alloc(src, &c->sorted.id, n)) || (rc = dev_alloc(src, &c->nmask.words, (size_t)(kMaskWords + 2) * n)) ||
       (rc = dev_alloc(src, &c->nmask.ncand, n)) || (rc = dev_alloc(src, &c->nmask.nnb, n)))
     return rc;
@@ -497,7 +497,7 @@ int sph_destroy(sph_context* c) {
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->wait_event) (void)hipEventDestroy(c->wait_event);
   free_state(&c->cur);
-  (void)hipFree(c->sorted.pos); (void)hipFree(c->sorted.rec); (void)hipFree(c->sorted.id);
+  (void)hipFree(c->sorted.pos3); (void)hipFree(c->sorted.rec); (void)hipFree(c->sorted.id);
   (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand); (void)hipFree(c->nmask.nnb);
   (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.block_sums);
   (void)hipFree(c->grid.cell_of); (void)hipFree(c->grid.rank_of); (void)hipFree(c->grid.src_of);

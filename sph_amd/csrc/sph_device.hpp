@@ -17,6 +17,12 @@ __device__ inline int cell_coord(float x, float cell, int gn) {
 }
 
 __device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
+// Grid-sorted position of slot j (w = 0).
+__device__ inline float4 sorted_pos(const Sorted& st, int j) {
+  const float* p = st.pos3 + 3 * (size_t)j;
+  return make_float4(p[0], p[1], p[2], 0.0f);
+}
+
 __device__ inline float dist2_to(const float4& a, const float4& b, float& dx, float& dy, float& dz) {
   dx = a.x - b.x;  // :140-142
   dy = a.y - b.y;

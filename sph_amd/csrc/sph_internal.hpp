@@ -55,7 +55,7 @@ struct ParticleRec {
 // `pos` is allocated that much longer than the particle capacity.
 constexpr int kSearchOverread = 4;
 struct Sorted {
-  float4* pos;
+  float* pos3;  // x y z packed, 12 bytes per particle: four candidates of the search are three 16-byte loads
   ParticleRec* rec;
   int32_t* id;
 };

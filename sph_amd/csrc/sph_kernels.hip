@@ -290,7 +290,9 @@ __global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict
   }
   for (; t < e; t++) r += id_prov[t] < my;
   const int d = b + r;
-  out.pos[d] = pos;
+  out.pos3[3 * (size_t)d + 0] = pos.x;
+  out.pos3[3 * (size_t)d + 1] = pos.y;
+  out.pos3[3 * (size_t)d + 2] = pos.z;
   out.rec[d].pos = pos;  // w receives 1/density
   out.rec[d].vel = vel;  // w receives the density
   out.id[d] = my;

@@ -1,7 +1,7 @@
 // Neighbour sweeps for gfx950: neighbour search, density pass and force+integration pass of one SPH step
 // (reference compute/compute.cpp:131-150 and :153-319).  Compile with -ffp-contract=off.
 //
-// The sweeps read the grid-sorted copy of the state, packed for gathers: one float4 per particle for the
+// The sweeps read the grid-sorted copy of the state, packed for gathers: 12 bytes per particle for the
 // position (search, density) and a 32-byte record with position and velocity + density (force).  Cells are
 // linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the slab axis, slowest): the 27-cell stencil of a
 // particle is 9 runs of up to 3 z-adjacent cells, each run ONE contiguous slot range.  Runs are visited
@@ -10,7 +10,7 @@
 //
 // Default (SWEEP_MASKED) pipeline, one lane per particle in every kernel:
 //   k_neighbours  the only kernel that tests distances: walks the flattened stencil four candidates per trip
-//                 (independent 16-byte gathers) and records WHICH candidates satisfy sqrtf(r2) <= h as a
+//                 (48 packed bytes, three 16-byte gathers) and records WHICH candidates satisfy sqrtf(r2) <= h as a
 //                 bitmask per particle, plus the candidate and neighbour counts;
 //   k_density     walks the set bits: every loop trip is a true neighbour, so the sqrt / double-precision
 //                 kernel arithmetic runs with the wave's lanes busy instead of ~20 % of them;
@@ -29,7 +29,11 @@ namespace sph {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kAhead = 4;  // candidates fetched per loop trip of the search: independent loads in flight per lane
+constexpr int kAhead = 4;  // candidates fetched per loop trip of the search
+static_assert(kAhead == 4, "the search unpacks four packed positions out of three 16-byte words");
+struct __attribute__((aligned(4))) Quad {  // 16 bytes at dword alignment
+  float a, b, c, d;
+};
 constexpr int kMaskBits = 32 * kMaskWords;
 
 __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
@@ -129,7 +133,7 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 
 // ---- neighbour search ---------------------------------------------------------------------------------------------
 // The only kernel that tests distances.  One lane per particle walks its flattened stencil four candidates per
-// trip (four independent 16-byte gathers in flight) and packs the outcomes into the particle's mask:
+// trip (three independent 16-byte gathers in flight) and packs the outcomes into the particle's mask:
 // bit q <=> the q-th candidate passes sqrtf(r2) <= h, tested as r2 <= r2_max with
 // r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
 // WITH_DENSITY (fast arithmetic): the density is accumulated on the spot, rho_i = (m c_poly6)_fp32 * sum over the
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
   const int s = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x + threadIdx.x;
   if (s >= hi) return;
-  const float4 pi = st.pos[s];
+  const float4 pi = sorted_pos(st, s);
   const int trips = fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
   unsigned word = 0;
   int q = 0, cnt = 0;  // q: candidates seen so far = index of the next one in the flattened stencil
@@ -161,10 +165,14 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
     const int m = qe - q < kAhead ? qe - q : kAhead;
     // Always fetch kAhead consecutive slots from one base address: past the end of the run they belong to the
     // next cell or to the array's padding, and their outcomes are masked off below.
-    const float4* base = st.pos + (shift + q);
+    // kAhead = 4 packed positions are 48 bytes: three 16-byte loads (dword-aligned, as global loads may be)
+    const Quad* base = reinterpret_cast<const Quad*>(st.pos3 + 3 * (size_t)(shift + q));
+    const Quad w0 = base[0], w1 = base[1], w2 = base[2];
     float4 cand[kAhead];
-#pragma unroll
-    for (int u = 0; u < kAhead; u++) cand[u] = base[u];
+    cand[0] = make_float4(w0.a, w0.b, w0.c, 0.0f);
+    cand[1] = make_float4(w0.d, w1.a, w1.b, 0.0f);
+    cand[2] = make_float4(w1.c, w1.d, w2.a, 0.0f);
+    cand[3] = make_float4(w2.b, w2.c, w2.d, 0.0f);
     unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < kAhead; u++) {
@@ -293,7 +301,7 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
                   pj = st.rec[j].pos;
                   vj = st.rec[j].vel;
                 } else {
-                  pj = st.pos[j];
+                  pj = sorted_pos(st, j);
                 }
               },
               visit);
@@ -303,7 +311,7 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
       const int b = rt.shift[k][col] + q, e = rt.shift[k][col] + rt.qend[k][col];
       q = rt.qend[k][col];
       for (int j = b; j < e; j++) {
-        const float4 pj = st.pos[j];
+        const float4 pj = sorted_pos(st, j);
         if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) {
           if (WITH_VEL) visit(st.rec[j].pos, st.rec[j].vel);  // the record's w components carry 1/density and density
           else visit(pj, pj);
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   const int col = threadIdx.x;
   const int s = first + col;
   if (s >= hi) return;
-  const float4 pi = st.pos[s];
+  const float4 pi = sorted_pos(st, s);
   const CellCoord cc = decode_cell(P, cell_s[s]);
   if (MODE == SWEEP_MASKED) fill_runs(P, start, cc, RunTable{rt_shift, rt_qend});  // own column: no barrier needed
   float acc = 0.0f;
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
       for (int j = c.j; j < c.e; j++) {
-        const float r2 = dist2_to(pi, st.pos[j], dx, dy, dz);
+        const float r2 = dist2_to(pi, sorted_pos(st, j), dx, dy, dz);
         if (r2 <= P.r2_max) add(r2);
       }
     }
@@ -363,7 +371,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
       RunCursor c{-1, 0, 0};
       while (next_run(P, start, cc, c)) {
         for (int j = c.j; j < c.e; j++) {
-          const float r2 = dist2_to(pi, st.pos[j], dx, dy, dz);
+          const float r2 = dist2_to(pi, sorted_pos(st, j), dx, dy, dz);
           const int idj = st.id[j];
           if (r2 <= P.r2_max && idj > last && idj < best) {
             best = idj;
@@ -413,7 +421,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   const int s = base + first + col;
   const int o = s - own_base;
   if (s >= bound) return;
-  const float4 pi4 = st.pos[s];
+  const float4 pi4 = sorted_pos(st, s);
   const float4 vi4 = st.rec[s].vel;  // w = density
   const float rho_i = vi4.w;
   const float pi = P.c2 * (rho_i - P.rho0);  // :158
@@ -438,8 +446,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
       for (int j = c.j; j < c.e; j++) {
-        const float r2 = dist2_to(pi4, st.pos[j], dx, dy, dz);
-        if (r2 <= P.r2_max) add_pair(st.pos[j], st.rec[j].vel);
+        const float r2 = dist2_to(pi4, sorted_pos(st, j), dx, dy, dz);
+        if (r2 <= P.r2_max) add_pair(sorted_pos(st, j), st.rec[j].vel);
       }
     }
   } else {  // SWEEP_EXACT: ascending particle id
@@ -449,7 +457,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
       RunCursor c{-1, 0, 0};
       while (next_run(P, start, cc, c)) {
         for (int j = c.j; j < c.e; j++) {
-          const float r2 = dist2_to(pi4, st.pos[j], dx, dy, dz);
+          const float r2 = dist2_to(pi4, sorted_pos(st, j), dx, dy, dz);
           const int idj = st.id[j];
           if (r2 <= P.r2_max && idj > last && idj < best) {
             best = idj;
@@ -458,7 +466,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
         }
       }
       if (bj < 0) break;
-      add_pair(st.pos[bj], st.rec[bj].vel);
+      add_pair(sorted_pos(st, bj), st.rec[bj].vel);
       last = best;
     }
   }
