@@ -306,6 +306,12 @@ int sph_slab_column_counts(sph_context* ctx, int32_t* counts, int capacity, int*
 /* sph_slab_column_counts and sph_slab_max_column_shift in one round trip to the device: what a load
  * balancer asks for every time it runs. */
 int sph_slab_load_info(sph_context* ctx, int32_t* counts, int capacity, int* ncols, float* max_shift);
+/* The same plus work[col] = sum over the column's particles of (9 + neighbours at the last search): what a step costs
+ * is about proportional to that, not to the particle count (a particle in fluid compressed to 50 neighbours costs
+ * 2.7 times one at the rest density's 13).  Entry k describes global column *first_col + k: the own columns AT THE LAST
+ * SORT, which lag sph_slab_set_next_columns by a step. */
+int sph_slab_load_work(sph_context* ctx, int32_t* counts, int32_t* work, int capacity, int* first_col, int* ncols,
+                       float* max_shift);
 /* Total number of RECEIVED records so far whose x-column lay outside this context's local grid (own
  * columns +- 2): particles that no context integrates any more.  Must stay 0; it cannot stay 0 when
  * particles cross more columns per step than the neighbouring slab is wide (see

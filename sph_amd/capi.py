@@ -67,6 +67,8 @@ _SIGNATURES = [
     ("sph_slab_lost", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     ("sph_slab_max_column_shift", C.c_int, [_CTX, C.POINTER(C.c_float)]),
     ("sph_slab_load_info", C.c_int, [_CTX, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ("sph_slab_load_work", C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_float)]),
     ("sph_comm_unique_id", C.c_int, [C.c_void_p]),
     ("sph_slab_attach_rccl", C.c_int, [_CTX, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("sph_slab_attach_local", C.c_int, [_CTX, _CTX, _CTX, C.c_int]),
@@ -387,6 +389,16 @@ class SlabSimulation:
         n, v = C.c_int(), C.c_float()
         _check(self.lib.sph_slab_load_info(self._ctx, out.ctypes.data, out.size, C.byref(n), C.byref(v)))
         return out[:n.value], float(v.value)
+
+    def load_work(self):
+        """(first column, particles per column, work per column = sum of 9 + neighbours, max column shift) for the own
+        columns of the last sort: one round trip."""
+        gn = self.columns()[2]
+        counts, work = np.empty(gn, np.int32), np.empty(gn, np.int32)
+        first, n, v = C.c_int(), C.c_int(), C.c_float()
+        _check(self.lib.sph_slab_load_work(self._ctx, counts.ctypes.data, work.ctypes.data, gn, C.byref(first), C.byref(n),
+                                           C.byref(v)))
+        return first.value, counts[:n.value], work[:n.value], float(v.value)
 
     def max_column_shift(self):
         """Columns a particle can cross in the next step: max |vx| * dt / cell over this slab's particles."""

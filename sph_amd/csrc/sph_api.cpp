@@ -70,7 +70,7 @@ struct sph_context {
   int32_t* d_counters = nullptr;      // [0],[1] pack counters  [2] own count  [3] trash count after a step
                                       // [4] stray received records (cumulative)  [5] max column shift (float bits)
   int32_t* h_counters = nullptr;      // pinned mirror
-  int32_t* d_colcounts = nullptr;     // [cols_capacity + 4]
+  int32_t* d_colcounts = nullptr;     // [2 * (cols_capacity + 4)]: particles per local column, then work per local column
   bool n_pending = false;             // true count of `cur` still travelling to h_counters[2]
   // Records for the neighbours, packed right behind the force pass of a step into buffers of the context's own
   // (the counts travel home with the own count): the next sph_slab_pack then only copies them out.
@@ -440,7 +440,7 @@ int create_common(const sph_params* params, int n_max, int device, bool slab, in
   if ((rc = dev_alloc(heap, &c->dbg.force, 3 * n)) || (rc = dev_alloc(heap, &c->dbg.ncount, n)) ||
       (rc = dev_alloc(heap, &c->stage_pos, 3 * n)) || (rc = dev_alloc(heap, &c->stage_vel, 3 * n)) ||
       (rc = dev_alloc(heap, (uint32_t**)&c->stage_dbg, 6 * n)) || (rc = dev_alloc(heap, &c->d_counters, 8)) ||
-      (rc = dev_alloc(heap, &c->d_colcounts, (size_t)cap_cols + 4)))
+      (rc = dev_alloc(heap, &c->d_colcounts, 2 * ((size_t)cap_cols + 4))))
     return bail(rc);
   if (hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(SPH_ERR_HIP, "hipHostMalloc failed"));
@@ -957,8 +957,8 @@ int sph_slab_append(sph_context* c, const float* d_rec, int n_rec) {
   return SPH_OK;
 }
 
-// Column counts and (optionally) the column shift in one round trip to the device.
-static int load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, float* max_shift) {
+// Column counts and (optionally) work per column and the column shift, in one round trip to the device.
+static int load_info(sph_context* c, int32_t* counts, int32_t* work, int capacity, int* ncols, float* max_shift) {
   if (!c || !counts) return fail(SPH_ERR_INVALID, "NULL argument");
   if (!c->stepped) return fail(SPH_ERR_STATE, "column counts come from the last step's sort: step first");
   HIP_TRY(hipSetDevice(c->device));
@@ -975,21 +975,33 @@ static int load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, 
     HIP_TRY(hipMemcpyAsync(c->h_counters + 5, c->d_counters + 5, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   }
   launch_column_counts(c->stream, c->grid.start, G.nx, G.ny * G.nz, c->d_colcounts);
+  int32_t* d_work = c->d_colcounts + c->cols_capacity + 4;
+  if (work) launch_column_work(c->stream, c->grid.start, G.own_lo, G.own_hi, G.ny * G.nz, c->nmask.nnb, d_work);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(counts, c->d_colcounts + G.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost,
                          c->stream));
+  if (work)
+    HIP_TRY(hipMemcpyAsync(work, d_work + G.own_lo, (size_t)own * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (max_shift) memcpy(max_shift, c->h_counters + 5, sizeof(float));
   return SPH_OK;
 }
 
 int sph_slab_column_counts(sph_context* c, int32_t* counts, int capacity, int* ncols) {
-  return load_info(c, counts, capacity, ncols, nullptr);
+  return load_info(c, counts, nullptr, capacity, ncols, nullptr);
 }
 
 int sph_slab_load_info(sph_context* c, int32_t* counts, int capacity, int* ncols, float* max_shift) {
   if (!max_shift) return fail(SPH_ERR_INVALID, "NULL argument");
-  return load_info(c, counts, capacity, ncols, max_shift);
+  return load_info(c, counts, nullptr, capacity, ncols, max_shift);
+}
+
+int sph_slab_load_work(sph_context* c, int32_t* counts, int32_t* work, int capacity, int* first_col, int* ncols,
+                       float* max_shift) {
+  if (!max_shift || !work || !first_col) return fail(SPH_ERR_INVALID, "NULL argument");
+  const int rc = load_info(c, counts, work, capacity, ncols, max_shift);
+  if (rc == SPH_OK) *first_col = c->sorted_col_lo;
+  return rc;
 }
 
 int sph_slab_lost(sph_context* c, int64_t* lost) {
@@ -1094,7 +1106,7 @@ int post_exchange(sph_context* c, const int cap_out[2], const int cap_in[2]) {
 // Completes the exchange: the ONE host wait of a step (on the communication stream; the compute stream keeps running
 // the interior force pass), then the received records join the particle set behind the own particles.
 // `own_known` >= 0: the own count is that (halo exchange of an uploaded state); < 0: it comes home with the counters.
-int complete_exchange(sph_context* c, int own_known) {
+int complete_exchange(sph_context* c, int own_known, bool apply_next) {
   const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
   const bool face[2] = {l, r};
   int n_in[2] = {0, 0};
@@ -1153,6 +1165,13 @@ int complete_exchange(sph_context* c, int own_known) {
   c->missed = c->h_counters[6];
   if ((long long)own + n_in[0] + n_in[1] > c->n_max)
     return fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", own, n_in[0] + n_in[1], c->n_max);
+  // The records just exchanged were packed for the faces of the NEXT step: those take effect now, before the received
+  // records are checked against the local grid (kernels already launched carry their own copy of the old one).
+  if (apply_next && c->next_pending) {
+    c->next_pending = false;
+    const int rc = set_grid(c, &c->params, c->next_lo, c->next_hi);
+    if (rc != SPH_OK) return rc;
+  }
   // the received records join the set on the compute stream, behind whatever it is still doing
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
   c->n = own;
@@ -1272,7 +1291,7 @@ int sph_slab_halo_end(sph_context* c) {
   if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
   if (!c->in_flight) return fail(SPH_ERR_STATE, "no exchange in flight");
   HIP_TRY(hipSetDevice(c->device));
-  return complete_exchange(c, c->n);
+  return complete_exchange(c, c->n, false);
 }
 
 // One time step, records for the next one packed and under way before the interior columns are advanced.
@@ -1352,14 +1371,7 @@ int sph_slab_step_end(sph_context* c) {
   if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
   if (!c->in_flight) return fail(SPH_ERR_STATE, "no exchange in flight");
   HIP_TRY(hipSetDevice(c->device));
-  int rc = complete_exchange(c, -1);
-  if (rc) return rc;
-  if (c->next_pending) {  // the records just exchanged were packed for the new faces: they take effect now
-    c->next_pending = false;
-    rc = set_grid(c, &c->params, c->next_lo, c->next_hi);
-    c->halo_current = rc == SPH_OK;
-  }
-  return rc;
+  return complete_exchange(c, -1, true);
 }
 
 int sph_slab_exchange_step(sph_context* c) {

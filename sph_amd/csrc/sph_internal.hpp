@@ -26,7 +26,6 @@ struct DevParams {
                              // (faces first, interior while the halo records travel)
   int dens_lo, dens_hi;      // local x-columns whose density is needed: own plus one ghost column per side
   int tension;               // surface-tension term on/off
-  int xcd_run;               // consecutive workgroups of a sweep that share an XCD (set by the sweep launchers)
   // fp32 products of mass/viscosity and the kernel coefficients, for the fast-arithmetic sweeps (rounded once on
   // the host from the double coefficients above)
   float k_dens;              // m * c_poly6                      density, compute.cpp:68,146
@@ -133,6 +132,8 @@ void launch_join_aos(hipStream_t s, const State& st, int n, float* pos, float* v
 void launch_fill_lattice(hipStream_t s, const State& st, long long first, int n, int ny, int nz, double spacing,
                          double jitter, unsigned long long seed, const double origin[3]);
 void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, int32_t* out);
+void launch_column_work(hipStream_t s, const int32_t* start, int col_lo, int col_hi, int cpc, const int32_t* nnb,
+                        int32_t* out);
 
 // Camera of a rendered frame in the form the splat kernel uses: view = m * position + t.
 struct RenderCamera {

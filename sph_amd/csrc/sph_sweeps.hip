@@ -40,7 +40,7 @@ __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); 
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.  Remap the block index so that
 // every XCD works on runs of `run` CONSECUTIVE blocks of the sorted particle range instead of every eighth block.
-// The launchers set run = blocks / (8 * kXcdWindows): each XCD sweeps kXcdWindows contiguous windows of the
+// With run = blocks / (8 * kXcdWindows) (range_first_slot below) each XCD sweeps kXcdWindows contiguous windows of the
 // domain one after the other, so the blocks it has in flight at any time are neighbours in the sorted order and
 // their stencils (three x-planes of cells) overlap in its L2.  Several windows per XCD rather than one spread
 // crowded and empty regions of the tank over the XCDs.  Measured on the 1M dam break, L2 misses of the force
@@ -53,6 +53,23 @@ __device__ inline int xcd_block(int b, int nb, int run) {
   if (b >= nb / span * span) return b;
   const int xcd = b & 7, i = b >> 3;
   return ((i / run) * 8 + xcd) * run + i % run;
+}
+
+// First slot offset of this block within a range of `nslots` slots that a launch of at least ceil(nslots / B) blocks
+// covers, or -1 for a block beyond it.  The launch is sized for an upper bound known to the host (all particles); the
+// range (some columns of them) is known on the device only.  The windows are laid over the blocks that HAVE work:
+// hardware deals block indices round-robin to the XCDs whether they exit at once or not, so the first
+// ceil(nslots / B) indices are spread evenly, and mapping those keeps every XCD busy for any range.
+// A window should be a few x-columns deep, or most of what its blocks gather (three columns per block) is fetched for
+// that window alone: ranges of fewer than 24 * kXcdWindows columns (slabs, face ranges) get fewer windows per XCD.
+__device__ inline int range_first_slot(int nslots, int B, int ncols) {
+  const int nact = (nslots + B - 1) / B;
+  if ((int)blockIdx.x >= nact) return -1;
+  int windows = ncols / 24;
+  windows = windows < 1 ? 1 : (windows > kXcdWindows ? kXcdWindows : windows);
+  int run = nact / (8 * windows);
+  run = run > 0 ? run : 1;
+  return xcd_block(blockIdx.x, nact, run) * B;
 }
 
 struct CellCoord {
@@ -146,8 +163,9 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
-  const int s = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x + threadIdx.x;
-  if (s >= hi) return;
+  const int off = range_first_slot(hi - lo, kBlock, P.dens_hi - P.dens_lo);
+  const int s = lo + off + threadIdx.x;
+  if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   const int trips = fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
   unsigned word = 0;
@@ -333,10 +351,11 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
-  const int first = lo + xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x;
+  const int off = range_first_slot(hi - lo, kBlock, P.dens_hi - P.dens_lo);
+  const int first = lo + off;
   const int col = threadIdx.x;
   const int s = first + col;
-  if (s >= hi) return;
+  if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   const CellCoord cc = decode_cell(P, cell_s[s]);
   if (MODE == SWEEP_MASKED) fill_runs(P, start, cc, RunTable{rt_shift, rt_qend});  // own column: no barrier needed
@@ -409,8 +428,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     n_own_out[0] = own_bound - own_base;           // particles this context keeps
     n_own_out[1] = start[real + 1] - start[real];  // trash cell: particles outside the local grid
   }
-  const int first = xcd_block(blockIdx.x, gridDim.x, P.xcd_run) * blockDim.x;
-  if (base + first >= bound) return;  // whole block beyond the range (uniform: before any barrier)
+  const int first = range_first_slot(bound - base, kBlock, P.force_hi - P.force_lo);
+  if (first < 0) return;  // whole block beyond the range (uniform: before any barrier)
   int col = threadIdx.x;
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
@@ -488,17 +507,10 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
 
 }  // namespace
 
-static DevParams with_xcd_run(const DevParams& P0, int n) {
-  DevParams P = P0;
-  const int run = div_up(n, kBlock) / (8 * kXcdWindows);
-  P.xcd_run = run > 0 ? run : 1;
-  return P;
-}
-
 void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
                        const NeighbourMask& nm, bool with_density, int32_t* ncount) {
   if (n <= 0) return;
-  const DevParams P = with_xcd_run(P0, n);
+  const DevParams& P = P0;
   if (with_density)
     hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount);
   else
@@ -508,7 +520,7 @@ void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int
 void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
                     int32_t* ncount, const NeighbourMask& nm, SweepMode mode) {
   if (n <= 0) return;
-  const DevParams P = with_xcd_run(P0, n);
+  const DevParams& P = P0;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
     hipLaunchKernelGGL((k_density<SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
@@ -524,7 +536,7 @@ void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const St
                   const GridBuffers& g, float* force_dbg, int32_t* n_own_out, const NeighbourMask& nm,
                   SweepMode mode) {
   if (n <= 0) return;
-  const DevParams P = with_xcd_run(P0, n);
+  const DevParams& P = P0;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
     hipLaunchKernelGGL((k_force<SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);

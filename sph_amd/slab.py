@@ -342,13 +342,16 @@ def step_local_slabs_overlapped(backends):
         b.step_end()
 
 
-def rebalance_next_local_slabs(backends, cuts):
-    """Load balancing for the library-driven exchange: the new cuts apply to the records of the next step."""
+def rebalance_next_local_slabs(backends, cuts, by="work"):
+    """Load balancing for the library-driven exchange: the new cuts apply to the records of the next step.
+    by="work" balances the sum of (9 + neighbours) per slab - what a step costs - instead of the particle count."""
     hist = np.zeros(cuts[-1], np.int64)
+    shift = 0.0
     for r, b in enumerate(backends):
-        c = b.column_counts()
-        hist[cuts[r]:cuts[r] + len(c)] = c
-    shift = max(b.max_column_shift() for b in backends)
+        first, counts, work, s = b.load_work()  # the columns of the last sort: they lag the cut planes by a step
+        c = work if by == "work" else counts
+        hist[first:first + len(c)] = c
+        shift = max(shift, s)
     new = rebalance_cuts(cuts, hist, min_cols=min_columns_for_shift(shift))
     for r, b in enumerate(backends):
         b.set_face_shift(shift)
@@ -361,10 +364,11 @@ class LibraryRunner:
     columns).  torch.distributed is used only off the data path: to hand the communicator id to the ranks and to
     all-reduce the column histogram when the cut planes are rebalanced."""
 
-    def __init__(self, backend, rank, nranks, cuts, rebalance_every=0, group=None, reduce_device=None):
+    def __init__(self, backend, rank, nranks, cuts, rebalance_every=0, group=None, reduce_device=None, balance_by="work"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
+        self.balance_by = balance_by  # "work": sum of (9 + neighbours) per slab; "count": particles per slab
         self.backend, self.rank, self.nranks = backend, rank, nranks
         self.cuts = list(cuts)
         self.rebalance_every = rebalance_every
@@ -385,10 +389,11 @@ class LibraryRunner:
 
     def rebalance(self):
         b = self.backend
-        counts, own_shift = b.load_info()
+        lo, counts, work, own_shift = b.load_work()  # the columns of the last sort: they lag the cut planes by a step
+        if self.balance_by == "work":
+            counts = work
         ncols = self.cuts[-1]
         full = self.torch.zeros(ncols + self.nranks, dtype=self.torch.int64)
-        lo = self.cuts[self.rank]
         full[lo:lo + len(counts)] = self.torch.as_tensor(np.asarray(counts, dtype=np.int64))
         full[ncols + self.rank] = int(np.ceil(float(own_shift) * 1024.0))
         full = full.to(self.reduce_device)

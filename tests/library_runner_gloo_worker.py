@@ -30,9 +30,10 @@ class StandIn:
             self.cuts[self.rank], self.cuts[self.rank + 1] = self.next
             self.next = None
 
-    def load_info(self):
+    def load_work(self):
         lo, hi = self.cuts[self.rank], self.cuts[self.rank + 1]
-        return self.hist[lo:hi].astype(np.int32), self.shift
+        counts = self.hist[lo:hi].astype(np.int32)
+        return lo, counts, counts * 22, self.shift  # every particle at the rest density's 13 neighbours: work = 22 each
 
     def set_face_shift(self, v):
         self.face_shift = v
