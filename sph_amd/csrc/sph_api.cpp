@@ -1237,6 +1237,8 @@ int sph_slab_set_next_columns(sph_context* c, int col_lo, int col_hi) {
     return fail(SPH_ERR_CAPACITY, "%d columns exceed cols_capacity = %d", col_hi - col_lo, c->cols_capacity);
   if (abs(col_lo - c->col_lo) > 1 || abs(col_hi - c->col_hi) > 1)
     return fail(SPH_ERR_INVALID, "a face may move by at most one column per step");
+  if (c->in_flight)
+    return fail(SPH_ERR_STATE, "an exchange is in flight: its records were packed for the faces as they stood at sph_slab_step_begin");
   c->next_lo = col_lo;
   c->next_hi = col_hi;
   c->next_pending = col_lo != c->col_lo || col_hi != c->col_hi;

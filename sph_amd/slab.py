@@ -373,6 +373,7 @@ class LibraryRunner:
         self.cuts = list(cuts)
         self.rebalance_every = rebalance_every
         self.steps_done = 0
+        self._pending = None  # (tensor, work handle) of an all-reduce that the next step's end collects
         self.reduce_device = reduce_device if reduce_device is not None else torch.device("cpu")
 
     def prime(self):
@@ -384,10 +385,24 @@ class LibraryRunner:
         b.step_begin()
         b.step_end()
         self.steps_done += 1
+        if self._pending is not None:
+            self._finish_rebalance()
         if self.rebalance_every and self.steps_done % self.rebalance_every == 0 and self.nranks > 1:
-            self.rebalance()
+            self._post_rebalance()
+
+    def drain(self):
+        """Collect an all-reduce that is still outstanding (end of a run)."""
+        if self._pending is not None:
+            self._finish_rebalance()
 
     def rebalance(self):
+        """Synchronous form: histogram, all-reduce and new cut planes between two steps."""
+        self._post_rebalance()
+        self._finish_rebalance()
+
+    def _post_rebalance(self):
+        # The all-reduce (host, a few KB) is started now and collected after the NEXT step: it runs beside that step's
+        # launches instead of between two steps, at the price of cut planes that follow the load one step later.
         b = self.backend
         lo, counts, work, own_shift = b.load_work()  # the columns of the last sort: they lag the cut planes by a step
         if self.balance_by == "work":
@@ -397,9 +412,17 @@ class LibraryRunner:
         full[lo:lo + len(counts)] = self.torch.as_tensor(np.asarray(counts, dtype=np.int64))
         full[ncols + self.rank] = int(np.ceil(float(own_shift) * 1024.0))
         full = full.to(self.reduce_device)
-        self.dist.all_reduce(full, group=self.group)
+        self._pending = (full, self.dist.all_reduce(full, group=self.group, async_op=True))
+
+    def _finish_rebalance(self):
+        b = self.backend
+        full, work = self._pending
+        self._pending = None
+        work.wait()
         full = full.cpu().numpy()
-        hist, shift = full[:ncols], float(full[ncols:].max()) / 1024.0
+        ncols = self.cuts[-1]
+        # one column of margin: the shift was measured up to rebalance_every + 1 steps before the faces it sizes are used
+        hist, shift = full[:ncols], float(full[ncols:].max()) / 1024.0 + 1.0
         new = rebalance_cuts(self.cuts, hist, min_cols=min_columns_for_shift(shift))
         b.set_face_shift(shift)
         b.set_next_columns(new[self.rank], new[self.rank + 1])

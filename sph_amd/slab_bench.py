@@ -82,6 +82,8 @@ def main(args):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    if library:
+        runner.drain()
     tm = sim.timings()
     n_own = sim.last_own() if library else sim.n
     sent = 0.0 if library else float(runner.exchange.bytes_sent)
