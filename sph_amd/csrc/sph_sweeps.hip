@@ -35,6 +35,8 @@ struct __attribute__((aligned(4))) Quad {  // 16 bytes at dword alignment
   float a, b, c, d;
 };
 constexpr int kMaskBits = 32 * kMaskWords;
+constexpr int kTilePad = 32;                          // slots before and after the block's own kept in its record tile
+constexpr int kTileRecords = kBlock + 2 * kTilePad;   // 12 KB of LDS
 
 __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 
@@ -307,17 +309,34 @@ __device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const R
 // Calls visit(pos_j, vel_j) for every neighbour of particle slot s, in stencil order, from the mask written by
 // the neighbour search.  Falls back to testing again when the stencil holds more candidates than the mask has
 // bits (cells crowded beyond ~75 particles each) or the search left no mask.
+// A copy in LDS of the records of the slots [lo, lo + n): the block's own slots and a margin on either side.  The
+// neighbours a particle finds in its own (x, y) row of cells - the row that holds most of them - are its neighbours in
+// slot order too, so a good third of the force pass's gathers land in this window and are served from LDS instead of
+// through the vector cache.  Purely a cache: a slot outside the window is fetched from global memory as before.
+struct RecordTile {
+  const float4* pos;
+  const float4* vel;
+  int lo;
+  unsigned n;
+};
+
 template <bool WITH_VEL, class Visit>
 __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
                                           const NeighbourMask& nm, int s, const float4& pi, const RunTable& rt,
-                                          int col, Visit visit) {
+                                          int col, Visit visit, const RecordTile tile = RecordTile{nullptr, nullptr, 0, 0u}) {
   const int ncand = nm.ncand[s];
   if (ncand <= kMaskBits) {
     walk_mask(nm, s, nm.nnb[s], rt, col,
               [&](int j, float4& pj, float4& vj) {
                 if (WITH_VEL) {
-                  pj = st.rec[j].pos;
-                  vj = st.rec[j].vel;
+                  const unsigned t = (unsigned)(j - tile.lo);
+                  if (t < tile.n) {
+                    pj = tile.pos[t];
+                    vj = tile.vel[t];
+                  } else {
+                    pj = st.rec[j].pos;
+                    vj = st.rec[j].vel;
+                  }
                 } else {
                   pj = sorted_pos(st, j);
                 }
@@ -431,11 +450,20 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   const int first = range_first_slot(bound - base, kBlock, P.force_hi - P.force_lo);
   if (first < 0) return;  // whole block beyond the range (uniform: before any barrier)
   int col = threadIdx.x;
+  __shared__ float4 tile_pos[MODE == SWEEP_MASKED ? kTileRecords : 1], tile_vel[MODE == SWEEP_MASKED ? kTileRecords : 1];
+  RecordTile tile{tile_pos, tile_vel, 0, 0u};
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
     const int load = s_nat < bound ? nm.nnb[s_nat] : -1;
     if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTable{rt_shift, rt_qend});
-    col = lane_by_count(load);
+    tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
+    const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
+    tile.n = (unsigned)(tile_hi - tile.lo);
+    for (int t = threadIdx.x; t < (int)tile.n; t += kBlock) {
+      tile_pos[t] = st.rec[tile.lo + t].pos;
+      tile_vel[t] = st.rec[tile.lo + t].vel;
+    }
+    col = lane_by_count(load);  // its barriers also publish the tile
   }
   const int s = base + first + col;
   const int o = s - own_base;
@@ -460,7 +488,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTable{rt_shift, rt_qend}, col, add_pair);
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTable{rt_shift, rt_qend}, col, add_pair, tile);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
