@@ -35,8 +35,11 @@ struct __attribute__((aligned(4))) Quad {  // 16 bytes at dword alignment
   float a, b, c, d;
 };
 constexpr int kMaskBits = 32 * kMaskWords;
-constexpr int kTilePad = 32;                          // slots before and after the block's own kept in its record tile
-constexpr int kTileRecords = kBlock + 2 * kTilePad;   // 12 KB of LDS
+// Record tile of the force pass: the block's own slots (plus kTilePad on either side).  Measured at peak compression:
+// margins of 0 / 32 / 64 / 128 slots give 204 / 215 / 215 / 254 us - what a margin adds in hits it loses in resident
+// blocks (7 per CU without margin, with the run ends held as 16-bit).
+constexpr int kTilePad = 0;
+constexpr int kTileRecords = kBlock + 2 * kTilePad;  // 8 KB of LDS
 
 __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 
@@ -49,7 +52,7 @@ __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); 
 // pass: 270 MB per launch with 32-block runs, 87 MB with 4 windows, 70 MB with 1 window (which loses 7 % of
 // time to imbalance).  Bijective for any grid size (the tail that does not fill 8 runs keeps its index);
 // affects locality only, never results.
-constexpr int kXcdWindows = 4;
+constexpr int kXcdWindows = 8;
 __device__ inline int xcd_block(int b, int nb, int run) {
   const int span = 8 * run;
   if (b >= nb / span * span) return b;
@@ -109,13 +112,18 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
 // dependent global loads that would stall the whole wave each time one lane steps.  A run is stored by where it
 // sits in the particle's flattened candidate sequence: candidates [qend[k-1], qend[k]) are run k, and candidate q
 // of run k is sorted slot shift[k] + q.
-struct RunTable {
+// QE: int where the whole stencil is walked whatever its size (search, density); unsigned short in the force pass, which
+// consults the table only for stencils of at most kMaskBits candidates and wants the LDS for a record tile.
+template <class QE>
+struct RunTableT {
   int (*shift)[kBlock];  // first slot of run k minus the number of candidates before run k
-  int (*qend)[kBlock];   // number of candidates up to and including run k
+  QE (*qend)[kBlock];    // number of candidates up to and including run k (saturated at the largest QE)
 };
+using RunTable = RunTableT<int>;
 // Returns the number of kAhead-wide trips a walk over all runs takes.
+template <class QE>
 __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
-                                const RunTable& rt) {
+                                const RunTableT<QE>& rt) {
   const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
   // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
   // no branch, so that all 18 loads are issued before the first is waited for
@@ -137,7 +145,7 @@ __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ 
     rt.shift[k][threadIdx.x] = b[k] - q;
     q += len;
     trips += (len + kAhead - 1) / kAhead;
-    rt.qend[k][threadIdx.x] = q;
+    rt.qend[k][threadIdx.x] = sizeof(QE) == 2 ? (QE)(q < 65535 ? q : 65535) : (QE)q;
   }
   return trips;
 }
@@ -266,8 +274,8 @@ __device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count,
 // pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
 // of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
 // current one is evaluated, so their latency hides behind the pair arithmetic.
-template <class Load, class Visit>
-__device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const RunTable& rt, int col, Load load,
+template <class Table, class Load, class Visit>
+__device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const Table& rt, int col, Load load,
                                  Visit visit) {
   if (nn <= 0) return;
   // nn set bits are known to be there, so the walk needs no end-of-mask checks: the word after the current one
@@ -320,10 +328,11 @@ struct RecordTile {
   unsigned n;
 };
 
-template <bool WITH_VEL, class Visit>
+template <bool WITH_VEL, class Table, class Visit>
 __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, const int32_t* __restrict__ start,
-                                          const NeighbourMask& nm, int s, const float4& pi, const RunTable& rt,
-                                          int col, Visit visit, const RecordTile tile = RecordTile{nullptr, nullptr, 0, 0u}) {
+                                          const NeighbourMask& nm, int s, const float4& pi, const Table& rt,
+                                          int col, int cell_of_s, Visit visit,
+                                          const RecordTile tile = RecordTile{nullptr, nullptr, 0, 0u}) {
   const int ncand = nm.ncand[s];
   if (ncand <= kMaskBits) {
     walk_mask(nm, s, nm.nnb[s], rt, col,
@@ -344,10 +353,10 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
               visit);
   } else {
     float dx, dy, dz;
-    for (int k = 0, q = 0; k < 9; k++) {
-      const int b = rt.shift[k][col] + q, e = rt.shift[k][col] + rt.qend[k][col];
-      q = rt.qend[k][col];
-      for (int j = b; j < e; j++) {
+    const CellCoord cc = decode_cell(P, cell_of_s);  // the table may be saturated for a stencil this large
+    RunCursor c{-1, 0, 0};
+    while (next_run(P, start, cc, c)) {
+      for (int j = c.j; j < c.e; j++) {
         const float4 pj = sorted_pos(st, j);
         if (dist2_to(pi, pj, dx, dy, dz) <= P.r2_max) {
           if (WITH_VEL) visit(st.rec[j].pos, st.rec[j].vel);  // the record's w components carry 1/density and density
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<false>(P, st, start, nm, s, pi, RunTable{rt_shift, rt_qend}, col,
+    for_each_neighbour<false>(P, st, start, nm, s, pi, RunTable{rt_shift, rt_qend}, col, cell_s[s],
                               [&](const float4& pj, const float4&) { add(dist2_to(pi, pj, dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
@@ -436,7 +445,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
-  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
+  __shared__ int rt_shift[9][kBlock];  // used by the masked flavour only
+  __shared__ unsigned short rt_qend[9][kBlock];
   // This launch advances the slots of the x-columns [force_lo, force_hi), a part (usually all) of the own columns
   // [own_lo, own_hi); the new state is written compactly: own slot s goes to index s - (first own slot).
   int base, bound, own_base, own_bound;
@@ -455,7 +465,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
     const int load = s_nat < bound ? nm.nnb[s_nat] : -1;
-    if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTable{rt_shift, rt_qend});
+    if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTableT<unsigned short>{rt_shift, rt_qend});
     tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
     const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
     tile.n = (unsigned)(tile_hi - tile.lo);
@@ -488,7 +498,8 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTable{rt_shift, rt_qend}, col, add_pair, tile);
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTableT<unsigned short>{rt_shift, rt_qend}, col, cell_s[s], add_pair,
+                             tile);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
     while (next_run(P, start, cc, c)) {
