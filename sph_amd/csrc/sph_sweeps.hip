@@ -35,9 +35,10 @@ struct __attribute__((aligned(4))) Quad {  // 16 bytes at dword alignment
   float a, b, c, d;
 };
 constexpr int kMaskBits = 32 * kMaskWords;
-// Record tile of the force pass: the block's own slots (plus kTilePad on either side).  Measured at peak compression:
-// margins of 0 / 32 / 64 / 128 slots give 204 / 215 / 215 / 254 us - what a margin adds in hits it loses in resident
-// blocks (7 per CU without margin, with the run ends held as 16-bit).
+// Record tile of the force pass: the block's own slots (plus kTilePad on either side).  Measured at peak compression,
+// run ends held as 16-bit: 204 us without margin (7 blocks per CU), 215 us with 32 slots (6 blocks); with 32-bit run
+// ends 226 / 225 / 254 us for margins of 32 / 64 / 128 slots (5, 5, 4 blocks): what a margin adds in hits it loses in
+// resident blocks.
 constexpr int kTilePad = 0;
 constexpr int kTileRecords = kBlock + 2 * kTilePad;  // 8 KB of LDS
 
