@@ -274,7 +274,7 @@ __device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count,
 // Walks the set bits of particle slot s's candidate mask in order and calls visit(pos_j, vel_j) for each; load(j,
 // pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
 // of the sorted arrays, or positions in a staged tile).  The loads of the NEXT neighbour are issued before the
-// current one is evaluated, so their latency hides behind the pair arithmetic.
+// current one is evaluated (two neighbours ahead), so their latency hides behind the pair arithmetic.
 template <class Table, class Load, class Visit>
 __device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const Table& rt, int col, Load load,
                                  Visit visit) {
@@ -304,15 +304,19 @@ __device__ inline void walk_mask(const NeighbourMask& nm, int s, int nn, const T
     }
     return shift + q;
   };
-  float4 pj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vj = pj, pn = pj, vn = pj;
+  float4 pj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vj = pj, pn = pj, vn = pj, pm = pj, vm = pj;
   load(next_index(), pj, vj);
-  for (int i = 1; i < nn; i++) {
-    load(next_index(), pn, vn);
+  if (nn > 1) load(next_index(), pn, vn);
+  for (int i = 2; i < nn; i++) {  // two neighbours' records in flight behind the one being evaluated
+    load(next_index(), pm, vm);
     visit(pj, vj);
     pj = pn;
     vj = vn;
+    pn = pm;
+    vn = vm;
   }
   visit(pj, vj);
+  if (nn > 1) visit(pn, vn);
 }
 
 // Calls visit(pos_j, vel_j) for every neighbour of particle slot s, in stencil order, from the mask written by
