@@ -4,11 +4,27 @@ Weak scaling: the dam-break block holds `side`^3 particles PER GPU (N * side^3 i
 side round((N)^(1/3) * side)), in a tank twice the block's width.  `--side 200 --gpus 8` is the
 64M-particle dam break.  Every rank generates only its own lattice planes.
 """
+import contextlib
 import json
 import os
+import sys
 import time
 
 import numpy as np
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """Native libraries that chat on file descriptor 1 are sent to stderr: stdout carries the one JSON line."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1)
+        os.close(keep)
 
 
 def main(args):
@@ -32,7 +48,8 @@ def main(args):
     torch.cuda.set_device(dev_index)
     # library transport: the records travel over RCCL issued from C++; torch.distributed (gloo, host) only hands out the
     # communicator id and reduces the column histogram when cut planes move.  torch transport: everything through it.
-    dist.init_process_group("gloo" if (shared_gpu or library) else "nccl", rank=rank, world_size=world)
+    with _stdout_to_stderr():  # gloo reports its connections on stdout
+        dist.init_process_group("gloo" if (shared_gpu or library) else "nccl", rank=rank, world_size=world)
     device = torch.device("cuda", dev_index)
 
     side = int(round(args.side * world ** (1.0 / 3.0)))
@@ -59,7 +76,8 @@ def main(args):
     if library:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        sim.attach_rccl(uid[0], rank, world, rec_capacity)
+        with _stdout_to_stderr():  # RCCL announces its version on stdout when the communicator is created
+            sim.attach_rccl(uid[0], rank, world, rec_capacity)
         runner = slab.LibraryRunner(sim, rank, world, cuts, rebalance_every=args.rebalance_every)
         runner.prime()
     else:
