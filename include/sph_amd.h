@@ -167,7 +167,9 @@ int sph_num_particles(const sph_context* ctx);
 int sph_grid_dims(const sph_context* ctx, int dims[3]);
 
 /* Event timing: when enabled every kernel launch is bracketed by HIP events on the stream it
- * is launched on; sph_get_timings synchronises and returns the accumulated sums. */
+ * is launched on; sph_get_timings synchronises and returns the accumulated sums.  enable = 1 brackets every
+ * kernel category, enable = 2 the force pass only: an event record is a barrier packet on the queue, and twelve of
+ * them per step cost a 1M-particle step 8 % (0.476 against 0.436 ms), two cost 1 %. */
 int sph_enable_timing(sph_context* ctx, int enable);
 int sph_get_timings(sph_context* ctx, sph_timings* out);
 int sph_reset_timings(sph_context* ctx);

@@ -261,7 +261,8 @@ class Simulation:
         return rho, f, nc, cell
 
     def enable_timing(self, on=True):
-        _check(self.lib.sph_enable_timing(self._ctx, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel category, 2 the force pass only (cheap enough for a timed region)."""
+        _check(self.lib.sph_enable_timing(self._ctx, int(on)))
 
     def reset_timings(self):
         _check(self.lib.sph_reset_timings(self._ctx))
@@ -470,7 +471,8 @@ class SlabSimulation:
         return self.torch.empty((n, RECORD_WORDS), dtype=self.torch.float32, device=self.device)
 
     def enable_timing(self, on=True):
-        _check(self.lib.sph_enable_timing(self._ctx, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel category, 2 the force pass only (cheap enough for a timed region)."""
+        _check(self.lib.sph_enable_timing(self._ctx, int(on)))
 
     def reset_timings(self):
         _check(self.lib.sph_reset_timings(self._ctx))

@@ -102,7 +102,7 @@ struct sph_context {
   unsigned long long* frame_fb = nullptr;
   unsigned char* frame_rgb = nullptr;
   size_t frame_pixels = 0;
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 every kernel category, 2 the force pass only
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
   double acc_ms[CAT_N] = {0, 0, 0, 0, 0, 0, 0};
@@ -116,7 +116,7 @@ struct Timed {
   sph_context* c;
   EventPair p{};
   bool on;
-  Timed(sph_context* ctx, int cat) : c(ctx), on(ctx->timing) {
+  Timed(sph_context* ctx, int cat) : c(ctx), on(ctx->timing == 1 || (ctx->timing == 2 && cat == CAT_FORCE)) {
     if (!on) return;
     p.cat = cat;
     p.a = take();
@@ -734,7 +734,7 @@ int sph_grid_dims(const sph_context* c, int dims[3]) {
 
 int sph_enable_timing(sph_context* c, int enable) {
   if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
-  c->timing = enable != 0;
+  c->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   return SPH_OK;
 }
 
