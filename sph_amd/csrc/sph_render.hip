@@ -15,6 +15,7 @@ namespace sph {
 namespace {
 
 constexpr unsigned long long kEmptyPixel = ~0ull;
+constexpr float kMaxSplat = 512.0f;
 
 __global__ void k_frame_clear(unsigned long long* __restrict__ fb, int pixels) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,7 +43,10 @@ __global__ void k_frame_splat(State st, int n, RenderCamera cam, int width, int 
   const float py = 0.5f * (float)height - sy * vy / zc;  // row 0 is the top of the picture
   const float rp = sy * cam.radius / zc;                 // radius in pixels
   if (!(rp > 0.0f)) return;
-  int x0 = (int)floorf(px - rp), x1 = (int)ceilf(px + rp), y0 = (int)floorf(py - rp), y1 = (int)ceilf(py + rp);
+  // one lane draws one sphere: a sphere that fills more than kMaxSplat pixels either way (a particle at the near plane of
+  // a very large frame) is drawn out to that distance from its centre only, which bounds the lane's work
+  const float reach = rp < kMaxSplat ? rp : kMaxSplat;
+  int x0 = (int)floorf(px - reach), x1 = (int)ceilf(px + reach), y0 = (int)floorf(py - reach), y1 = (int)ceilf(py + reach);
   x0 = x0 < 0 ? 0 : x0;
   y0 = y0 < 0 ? 0 : y0;
   x1 = x1 > width - 1 ? width - 1 : x1;
