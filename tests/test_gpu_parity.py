@@ -490,3 +490,29 @@ def test_fill_lattice_matches_host_generator_bitwise():
         gp, _ = sim.download()
     assert dt < 0.1, f"16.8M particles took {dt:.3f} s to generate"
     assert np.isfinite(gp).all() and gp.min() >= 0.0 and gp.max() <= np.float32(big.tank_size)
+
+
+def test_event_timing_levels(oracle):
+    """sph_enable_timing: level 1 brackets every kernel category, level 2 the force pass only (what a timed region
+    can afford), 0 nothing; the accumulated particle and step counts follow the steps either way."""
+    pos, vel, p = scenes.dam_break(20)
+    with capi.Simulation(p, n_max=pos.shape[0]) as sim:
+        sim.upload(pos, vel)
+        sim.step(2)
+        sim.enable_timing(2)
+        sim.reset_timings()
+        sim.step(3)
+        t = sim.timings()
+        assert t["steps"] == 3 and t["particles"] == 3 * pos.shape[0]
+        assert t["force_ms"] > 0.0 and t["search_ms"] == 0.0 and t["hash_ms"] == 0.0 and t["reorder_ms"] == 0.0
+        sim.enable_timing(1)
+        sim.reset_timings()
+        sim.step(3)
+        t = sim.timings()
+        assert all(t[k] > 0.0 for k in ("hash_ms", "scan_ms", "reorder_ms", "search_ms", "force_ms"))
+        assert t["density_ms"] == 0.0  # fast arithmetic: the search accumulates the density, no separate pass
+        sim.enable_timing(0)
+        sim.reset_timings()
+        sim.step(2)
+        t = sim.timings()
+        assert t["force_ms"] == 0.0 and t["steps"] == 2
