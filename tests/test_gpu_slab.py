@@ -492,3 +492,24 @@ def test_eight_slabs_match_single_context_at_8m():
         assert bits_equal(bp[:k], rp[own]) and bits_equal(bv[:k], rv[own])
         b.close()
     assert np.all(seen == 1)
+
+
+def test_load_work_describes_the_own_columns_of_the_last_sort(oracle):
+    """sph_slab_load_work: per own column the particle count and the work figure sum(9 + neighbours); the counts add up
+    to the particles the slab advanced, the work to 9 per particle plus the neighbour counts of the same step, and the
+    first column is the slab's own first column at that sort."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=14)
+    backends, cuts = make_slabs(p, pos, vel, ids, 2, oracle)
+    attach_chain(backends)
+    slab.halo_local_slabs(backends)
+    slab.step_local_slabs_overlapped(backends)
+    for r, b in enumerate(backends):
+        first, counts, work, shift = b.load_work()
+        _, _, nc, _ = b.download_debug()
+        assert first == cuts[r] and len(counts) == cuts[r + 1] - cuts[r]
+        assert int(counts.sum()) == b.last_own() == nc.shape[0]
+        assert int(work.sum()) == 9 * int(counts.sum()) + int(nc.sum())
+        assert np.all(work >= 9 * counts) and shift >= 0.0
+    for b in backends:
+        b.close()
