@@ -346,6 +346,7 @@ int sph_slab_max_column_shift(sph_context* ctx, float* columns);
  * slabs; sph_slab_missed counts interior particles that reached a neighbour's halo anyway (must stay 0). */
 int sph_comm_unique_id(void* id128);  /* 128 bytes, made on one rank and handed to all (any out-of-band channel) */
 int sph_slab_attach_rccl(sph_context* ctx, const void* id128, int rank, int nranks, int rec_capacity);
+/* LOCAL: the neighbours are borrowed, not owned: destroy the contexts of a chain together, after the last exchange. */
 int sph_slab_attach_local(sph_context* ctx, sph_context* left, sph_context* right, int rec_capacity);
 int sph_slab_halo_begin(sph_context* ctx);
 int sph_slab_halo_end(sph_context* ctx);

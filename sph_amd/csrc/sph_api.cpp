@@ -1065,11 +1065,15 @@ int attach_common(sph_context* c, int rec_capacity) {
   if (c->xfer != sph_context::XFER_NONE) return fail(SPH_ERR_STATE, "the context is already attached to a transport");
   if (rec_capacity < 1024) return fail(SPH_ERR_INVALID, "rec_capacity must be at least 1024 records");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+  // an earlier attach that failed half-way may have left some of these behind: reuse what exists, replace the buffers
+  if (!c->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  if (!c->ev_pack) HIP_TRY(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+  if (!c->ev_comm) HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   const size_t bytes = (size_t)(rec_capacity + kHdr) * kRecordBytes;
   for (int k = 0; k < 2; k++) {
+    (void)hipFree(c->msg_out[k]);
+    (void)hipFree(c->msg_in[k]);
+    c->msg_out[k] = c->msg_in[k] = nullptr;
     HIP_TRY(hipMalloc((void**)&c->msg_out[k], bytes));
     HIP_TRY(hipMalloc((void**)&c->msg_in[k], bytes));
   }
