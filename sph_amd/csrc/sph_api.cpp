@@ -1120,6 +1120,9 @@ int complete_exchange(sph_context* c, int own_known, bool apply_next) {
       if (!face[k]) continue;
       sph_context* p = c->peer[k];
       if (!p || p->begun < c->begun) return fail(SPH_ERR_STATE, "the neighbouring context has not begun this exchange");
+      if (p->begun > c->begun)
+        return fail(SPH_ERR_STATE, "the neighbouring context has begun its next exchange and overwritten the message: "
+                                   "call begin on all contexts, then end on all of them");
       HIP_TRY(hipStreamWaitEvent(c->comm_stream, p->ev_pack, 0));
       HIP_TRY(hipMemcpyAsync(c->h_counters + 8 + k, p->d_counters + (1 - k), sizeof(int32_t), hipMemcpyDeviceToHost,
                              c->comm_stream));
