@@ -3,7 +3,7 @@ over the slabs when the cut planes balance particle counts, and when they balanc
    python scripts/gpu_balance_work.py <side> <slabs> <steps> <count|work>
 Per-slab device time = hash + scan + reorder + search + force of the slab's own kernels (HIP events), summed over the
 last 20 steps; prints worst / mean."""
-import json, os, sys
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sph_amd import slab, slab_local
@@ -12,15 +12,19 @@ side, nslabs, steps, by = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 
 p, backends, cuts = slab_local.build("dam_break", side, nslabs)
 slab.halo_local_slabs(backends)
 window = 20
+wall = [0.0] * nslabs  # host clock around begin + sync of each slab in the window (the kernels' brackets overlap in time
+                       # where a slab runs its face and interior columns side by side)
 for s in range(steps):
     if s == steps - window:
         for b in backends:
             b.enable_timing(True)
             b.reset_timings()
     if s >= steps - window:  # one slab at a time, so that no other slab's kernels share the GPU with the timed ones
-        for b in backends:
+        for k, b in enumerate(backends):
+            t0 = time.perf_counter()
             b.step_begin()
             b.sync()
+            wall[k] += time.perf_counter() - t0
         for b in backends:
             b.step_end()
     else:
@@ -41,7 +45,8 @@ own = [b.last_own() for b in backends]
 bad = {"lost": sum(b.lost() for b in backends), "missed": sum(b.missed() for b in backends)}
 t = np.array(t) / window
 print(json.dumps({"balance_by": by, "particles": side ** 3, "slabs": nslabs, "steps": steps,
-                  "slab_ms_per_step": [round(float(v), 3) for v in t], "worst_over_mean_time": float(t.max() / t.mean()),
+                  "slab_ms_per_step": [round(float(v), 3) for v in t],
+                  "slab_wall_ms_per_step": [round(w / window * 1e3, 3) for w in wall], "worst_over_mean_time": float(t.max() / t.mean()),
                   "sum_over_slabs_ms_per_step": {k: round(v, 4) for k, v in cats.items()}, "own": own, "worst_over_mean_particles": float(max(own) / np.mean(own)), "cuts": [int(c) for c in cuts],
                   "lost_or_missed": bad}))
 for b in backends:

@@ -1344,8 +1344,12 @@ int sph_slab_step_begin(sph_context* c) {
     own_out = nullptr;  // the first launch reports the own and trash counts
   };
   if ((rc = wait_for_readers(c))) return rc;
-  force_range(a_lo, a_hi);
-  if (b_hi > b_lo) force_range(b_lo, b_hi);
+  if (b_lo == a_hi && b_hi > b_lo && a_hi > a_lo) {
+    force_range(a_lo, b_hi);  // a slab so thin that its two face ranges touch: one launch (two half-sized ones cost tails)
+  } else {
+    force_range(a_lo, a_hi);
+    if (b_hi > b_lo) force_range(b_lo, b_hi);
+  }
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(int32_t), c->stream));
   {
     Timed t(c, CAT_OTHER);

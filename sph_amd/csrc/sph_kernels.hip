@@ -425,13 +425,25 @@ __global__ void k_slab_append(DevParams P, const float* __restrict__ rec, int n_
 
 // Largest |vx| * dt / cell over the particles: how many cell columns a particle can cross in the next step.
 // Non-negative floats order like their bit patterns, so the maximum is taken with an integer atomic.
+// One atomic per BLOCK of a fixed, small grid: atomics on a single word are served one after the other at the memory side
+// (about 11 ns each), so one per wave of a million particles would take 200 us.
+constexpr int kReduceBlocks = 512;
 __global__ void __launch_bounds__(kBlock) k_max_column_shift(DevParams P, State st, int n, int32_t* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float v = i < n ? fabsf(st.vx[i]) * P.dt / P.cell : 0.0f;
-  if (!(v >= 0.0f)) v = 0.0f;  // NaN
+  __shared__ float wmax[kBlock / 64];
+  float v = 0.0f;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float a = fabsf(st.vx[i]) * P.dt / P.cell;
+    v = a > v ? a : v;  // a NaN never wins
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(out, __float_as_int(v));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) v = fmaxf(v, wmax[w]);
+    if (v > 0.0f) atomicMax(out, __float_as_int(v));
+  }
 }
 
 __global__ void k_split_aos_ids(const float* __restrict__ pos, const float* __restrict__ vel,
@@ -535,16 +547,16 @@ __global__ void k_column_counts(const int32_t* __restrict__ start, int nx, int c
 // and force per neighbour); measured on the dam break, 0.225 ms per million particles at 13 neighbours and 0.60 ms at
 // 50 put a / b at 9.  One block per column; the column's slots are one contiguous range of the sorted arrays.
 constexpr int kWorkBase = 9;
+constexpr int kWorkChunks = 32;  // blocks per column: a slab has a few dozen columns of tens of thousands of particles each
 __global__ void __launch_bounds__(kBlock) k_column_work(const int32_t* __restrict__ start, int cpc,
                                                         const int32_t* __restrict__ nnb, int32_t* __restrict__ out) {
   const int c = blockIdx.x;
   const int lo = start[(size_t)c * cpc], hi = start[(size_t)(c + 1) * cpc];
-  long long acc = 0;
-  for (int s = lo + threadIdx.x; s < hi; s += kBlock) acc += kWorkBase + nnb[s];
-  int part = (int)(acc > 0x7fffffffLL ? 0x7fffffffLL : acc);
+  int acc = 0;  // a block's share of a column stays far below 2^31
+  for (int s = lo + blockIdx.y * kBlock + threadIdx.x; s < hi; s += kWorkChunks * kBlock) acc += kWorkBase + nnb[s];
   int tot;
-  block_exclusive_scan(part, &tot);
-  if (threadIdx.x == 0) out[c] = tot;
+  block_exclusive_scan(acc, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(&out[c], tot);
 }
 
 }  // namespace
@@ -607,7 +619,8 @@ void launch_slab_check_interior(hipStream_t s, const DevParams& P, const State& 
 
 void launch_max_column_shift(hipStream_t s, const DevParams& P, const State& st, int n, int32_t* out) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_max_column_shift, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, n, out);
+  const int blocks = div_up(n, kBlock) < kReduceBlocks ? div_up(n, kBlock) : kReduceBlocks;
+  hipLaunchKernelGGL(k_max_column_shift, dim3(blocks), dim3(kBlock), 0, s, P, st, n, out);
 }
 
 void launch_slab_append(hipStream_t s, const DevParams& P, const float* rec, int n_rec, const State& st, int at,
@@ -648,8 +661,9 @@ void launch_column_counts(hipStream_t s, const int32_t* start, int nx, int cpc, 
 void launch_column_work(hipStream_t s, const int32_t* start, int col_lo, int col_hi, int cpc, const int32_t* nnb,
                         int32_t* out) {
   if (col_hi <= col_lo) return;
-  hipLaunchKernelGGL(k_column_work, dim3(col_hi - col_lo), dim3(kBlock), 0, s, start + (size_t)col_lo * cpc, cpc, nnb,
-                     out + col_lo);
+  (void)hipMemsetAsync(out + col_lo, 0, (size_t)(col_hi - col_lo) * sizeof(int32_t), s);
+  hipLaunchKernelGGL(k_column_work, dim3(col_hi - col_lo, kWorkChunks), dim3(kBlock), 0, s, start + (size_t)col_lo * cpc,
+                     cpc, nnb, out + col_lo);
 }
 
 void launch_gather_aos(hipStream_t s, const State& st, int n, float* pos_aos, float* vel_aos) {
