@@ -358,6 +358,10 @@ int sph_slab_exchange_step(sph_context* ctx); /* begin + end: one context per pr
  * must call it between the same two steps; a face moves by at most one column per step. */
 int sph_slab_set_next_columns(sph_context* ctx, int col_lo, int col_hi);
 int sph_slab_set_face_shift(sph_context* ctx, float columns);
+/* How sph_slab_step_begin orders its force pass: 1 = face columns first, interior columns while the records travel;
+ * 0 = all own columns in one launch, records packed and posted afterwards (nothing hidden, but no small launches);
+ * 2 (default) = 1 for slabs of four million particles or more, 0 below.  Results are the same bits either way. */
+int sph_slab_set_overlap(sph_context* ctx, int mode);
 int sph_slab_missed(sph_context* ctx, int64_t* missed);
 
 /* The HIP stream (hipStream_t) all of the context's work is issued on; sph_set_stream makes the

@@ -80,6 +80,7 @@ _SIGNATURES = [
     ("sph_slab_exchange_step", C.c_int, [_CTX]),
     ("sph_slab_set_next_columns", C.c_int, [_CTX, C.c_int, C.c_int]),
     ("sph_slab_set_face_shift", C.c_int, [_CTX, C.c_float]),
+    ("sph_slab_set_overlap", C.c_int, [_CTX, C.c_int]),
     ("sph_slab_missed", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
@@ -458,6 +459,10 @@ class SlabSimulation:
 
     def set_next_columns(self, lo, hi):
         _check(self.lib.sph_slab_set_next_columns(self._ctx, int(lo), int(hi)))
+
+    def set_overlap(self, mode):
+        """0: one force launch, then pack; 1: faces first, interior beside the exchange; 2 (default): by slab size."""
+        _check(self.lib.sph_slab_set_overlap(self._ctx, int(mode)))
 
     def set_face_shift(self, columns):
         _check(self.lib.sph_slab_set_face_shift(self._ctx, float(columns)))

@@ -303,21 +303,24 @@ def test_column_counts_describe_the_last_sort_after_the_cuts_moved(oracle):
 
 # ---- exchange issued by the library (overlapped slab step) ------------------------------------------------------------------
 
-def attach_chain(backends, rec_capacity=1 << 16):
+def attach_chain(backends, rec_capacity=1 << 16, overlap=1):
+    """overlap=1 forces the split force pass (faces first, interior beside the exchange) that slabs this small would
+    not choose by themselves."""
     for r, b in enumerate(backends):
         b.attach_local(backends[r - 1] if r > 0 else None, backends[r + 1] if r < len(backends) - 1 else None,
                        rec_capacity)
+        b.set_overlap(overlap)
 
 
-@pytest.mark.parametrize("nslabs,rebalance", [(2, False), (3, True), (4, True)])
-def test_library_exchange_matches_single_context_bitwise(oracle, nslabs, rebalance):
+@pytest.mark.parametrize("nslabs,rebalance,overlap", [(2, False, 1), (3, True, 1), (4, True, 1), (3, True, 0), (2, False, 2)])
+def test_library_exchange_matches_single_context_bitwise(oracle, nslabs, rebalance, overlap):
     """Slabs whose records the library moves itself (faces first, interior columns while the records travel; LOCAL
     transport between contexts on one GPU), with moving cut planes: bit-identical to the single context per
     particle id, intermediates of the last step included."""
     p = default_params(flags=DBG)
     pos, vel, ids = moving_block(n_side=16)
     backends, cuts = make_slabs(p, pos, vel, ids, nslabs, oracle)
-    attach_chain(backends)
+    attach_chain(backends, overlap=overlap)
     slab.halo_local_slabs(backends)
     with capi.Simulation(p, n_max=ids.size) as single:
         single.upload(pos, vel)
