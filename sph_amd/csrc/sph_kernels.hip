@@ -305,23 +305,38 @@ constexpr int kRecWords = 7;
 // Every particle whose x-column is within two columns of (or beyond) a slab face is copied to the buffer
 // for the neighbour behind that face: it is either a migrant (new owner: the neighbour) or a ghost for it.
 // n_dev, when given, holds the true particle count on the device (the launch then covers an upper bound n).
-__global__ void k_slab_pack(DevParams P, State st, int n, const int32_t* __restrict__ n_dev, int col_lo, int col_hi,
-                            int has_left, int has_right, float* __restrict__ rec_left,
-                            float* __restrict__ rec_right, int cap, int32_t* __restrict__ counters) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (n_dev ? *n_dev : n)) return;
-  int g = cell_coord(st.x[i], P.cell, P.gnx);
-  bool to_left = has_left && g < col_lo + 2;
-  bool to_right = has_right && g >= col_hi - 2;
+__global__ void __launch_bounds__(kBlock) k_slab_pack(DevParams P, State st, int n, const int32_t* __restrict__ n_dev,
+                                                      int col_lo, int col_hi, int has_left, int has_right,
+                                                      float* __restrict__ rec_left, float* __restrict__ rec_right,
+                                                      int cap, int32_t* __restrict__ counters) {
+  __shared__ int block_base[2];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int count = n_dev ? *n_dev : n;
+  if ((int)(blockIdx.x * blockDim.x) >= count) return;  // whole block beyond the particles
+  bool to_left = false, to_right = false;
+  if (i < count) {
+    const int g = cell_coord(st.x[i], P.cell, P.gnx);
+    to_left = has_left && g < col_lo + 2;
+    to_right = has_right && g >= col_hi - 2;
+  }
+  // one global atomic per block and side: the block's records take consecutive places in the buffer
+  int n_left, n_right;
+  const int at_left = block_exclusive_scan(to_left ? 1 : 0, &n_left);
+  const int at_right = block_exclusive_scan(to_right ? 1 : 0, &n_right);
+  if (threadIdx.x == 0) {
+    block_base[0] = n_left ? atomicAdd(&counters[0], n_left) : 0;
+    block_base[1] = n_right ? atomicAdd(&counters[1], n_right) : 0;
+  }
+  __syncthreads();
   if (!to_left && !to_right) return;
-  float r[kRecWords] = {st.x[i], st.y[i], st.z[i], st.vx[i], st.vy[i], st.vz[i], __int_as_float(st.id[i])};
+  const float r[kRecWords] = {st.x[i], st.y[i], st.z[i], st.vx[i], st.vy[i], st.vz[i], __int_as_float(st.id[i])};
   if (to_left) {
-    int k = atomicAdd(&counters[0], 1);
+    const int k = block_base[0] + at_left;
     if (k < cap)
       for (int w = 0; w < kRecWords; w++) rec_left[(size_t)k * kRecWords + w] = r[w];
   }
   if (to_right) {
-    int k = atomicAdd(&counters[1], 1);
+    const int k = block_base[1] + at_right;
     if (k < cap)
       for (int w = 0; w < kRecWords; w++) rec_right[(size_t)k * kRecWords + w] = r[w];
   }
