@@ -335,6 +335,8 @@ int sph_slab_max_column_shift(sph_context* ctx, float* columns);
  *   sph_slab_step_begin   sort and search over own + received particles; force pass over the columns next to the
  *                         faces; records for the NEXT step packed from them and posted on the communication stream;
  *                         force pass over the interior columns meanwhile on the compute stream.  Asynchronous.
+ *                         (Slabs below four million particles advance all columns in one launch and post the records
+ *                         afterwards: see sph_slab_set_overlap.)
  *   sph_slab_step_end     waits for the exchange only (counts arrive in pinned host memory), sends the remainder of a
  *                         message that outgrew its agreed size, and queues the received records behind the interior
  *                         force pass.  Afterwards sph_num_particles is exact and the next step may begin.
