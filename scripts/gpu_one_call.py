@@ -1,0 +1,29 @@
+"""Development/measurement aid (GPU): the one-call entry (host arrays in, host arrays out: upload, one step, download)
+timed per call, pageable numpy memory as a host program would hold it.   python scripts/gpu_one_call.py <n> <calls>"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sph_amd import capi, scenes
+from sph_amd.params import SPH_FLAG_SURFACE_TENSION
+
+n, calls = int(sys.argv[1]), int(sys.argv[2])
+if n == 3000:
+    params = None                                   # the reference's own configuration
+    pos, vel = capi.fill_random_block(n)
+else:
+    side = round(n ** (1.0 / 3.0))
+    n = side ** 3
+    pos, vel, params = scenes.dam_break(side)
+    params.flags = SPH_FLAG_SURFACE_TENSION
+pos = np.ascontiguousarray(pos, np.float32)
+vel = np.ascontiguousarray(vel, np.float32)
+for _ in range(5):
+    capi.update_particles(pos, vel, params)
+t = []
+for _ in range(calls):
+    t0 = time.perf_counter()
+    capi.update_particles(pos, vel, params)
+    t.append(time.perf_counter() - t0)
+t = np.array(t) * 1e3
+print(json.dumps({"particles": n, "calls": calls, "ms_per_call_median": float(np.median(t)), "ms_per_call_mean": float(t.mean()),
+                  "particle_updates_per_s": n / (float(np.median(t)) * 1e-3), "bytes_over_pcie_per_call": 48 * n}))
