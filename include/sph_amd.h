@@ -364,7 +364,30 @@ int sph_slab_set_face_shift(sph_context* ctx, float columns);
  * 0 = all own columns in one launch, records packed and posted afterwards (nothing hidden, but no small launches);
  * 2 (default) = 1 for slabs of four million particles or more, 0 below.  Results are the same bits either way. */
 int sph_slab_set_overlap(sph_context* ctx, int mode);
+/* sph_slab_missed fetches the counter when called.  The interior check of a step runs behind that step's interior
+ * force pass, after the step's counters have gone home: the figure sph_slab_step_end keeps internally lags by a step,
+ * this call does not.  Cumulative either way. */
 int sph_slab_missed(sph_context* ctx, int64_t* missed);
+
+/* Message sizes.  A message's size must be known at both ends before it is posted, so both ends derive it from the
+ * true count of the previous message on that face (the sender knows what it sent, the receiver reads it from the
+ * header record): next = min(rec_capacity, max(min_records, roundup256(count * (1 + headroom) + 1))); defaults 0.25 and
+ * 1024.  A message that outgrows its size sends the remainder in a second round inside sph_slab_step_end.  Both
+ * transports run this protocol: LOCAL copies exactly the agreed number of records per round and refuses
+ * (SPH_ERR_STATE) when the two ends of a face disagree on a size.  Set the same values on every rank, before the first
+ * exchange.  An error from sph_slab_step_end / sph_slab_halo_end (SPH_ERR_CAPACITY: a face needed more than rec_capacity
+ * records, or own + received particles exceed n_max) ends the run on every rank: the failing context posts its
+ * remainder round first, so no neighbour is left waiting, and is left without a current halo. */
+int sph_slab_set_message_sizing(sph_context* ctx, float headroom, int min_records);
+/* Exchanges posted so far, how many of them needed a remainder round, and the sizes (records behind the header) of the
+ * next message to / from the left and right neighbour.  Any pointer may be NULL. */
+int sph_slab_exchange_stats(const sph_context* ctx, uint64_t* exchanges, uint64_t* remainder_rounds, int next_out[2],
+                            int next_in[2]);
+/* Diagnostic of the RCCL transport on the current device: a one-rank communicator is created and the exchange's group
+ * of ncclSend/ncclRecv is posted with this rank as both neighbours - words_left floats from d_send_left arrive in
+ * d_recv_left, words_right floats from d_send_right in d_recv_right (device buffers, none overlapping).  Synchronous. */
+int sph_comm_self_exchange(const float* d_send_left, float* d_recv_left, size_t words_left, const float* d_send_right,
+                           float* d_recv_right, size_t words_right);
 
 /* The HIP stream (hipStream_t) all of the context's work is issued on; sph_set_stream makes the
  * context issue on a caller-owned stream instead (e.g. the stream a communication library

@@ -82,6 +82,10 @@ _SIGNATURES = [
     ("sph_slab_set_face_shift", C.c_int, [_CTX, C.c_float]),
     ("sph_slab_set_overlap", C.c_int, [_CTX, C.c_int]),
     ("sph_slab_missed", C.c_int, [_CTX, C.POINTER(C.c_int64)]),
+    ("sph_slab_set_message_sizing", C.c_int, [_CTX, C.c_float, C.c_int]),
+    ("sph_slab_exchange_stats", C.c_int, [_CTX, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int * 2),
+                                          C.POINTER(C.c_int * 2)]),
+    ("sph_comm_self_exchange", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("sph_get_stream", C.c_int, [_CTX, C.POINTER(C.c_void_p)]),
     ("sph_set_stream", C.c_int, [_CTX, C.c_void_p]),
     ("sph_stream_wait", C.c_int, [_CTX, C.c_void_p]),
@@ -281,6 +285,15 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def comm_self_exchange(send_left, recv_left, send_right, recv_right):
+    """The slab exchange's RCCL group (send left, receive left, send right, receive right) with this rank as both
+    neighbours: torch CUDA float32 tensors, send and receive of a side equally long."""
+    assert send_left.numel() == recv_left.numel() and send_right.numel() == recv_right.numel()
+    _check(load().sph_comm_self_exchange(C.c_void_p(send_left.data_ptr()), C.c_void_p(recv_left.data_ptr()),
+                                         send_left.numel(), C.c_void_p(send_right.data_ptr()),
+                                         C.c_void_p(recv_right.data_ptr()), send_right.numel()))
+
+
 def global_cells(params):
     n = C.c_int()
     _check(load().sph_global_cells(C.byref(params), C.byref(n)))
@@ -471,6 +484,17 @@ class SlabSimulation:
         v = C.c_int64()
         _check(self.lib.sph_slab_missed(self._ctx, C.byref(v)))
         return v.value
+
+    def set_message_sizing(self, headroom, min_records):
+        """How the next message is sized from the last true count (the same on every rank)."""
+        _check(self.lib.sph_slab_set_message_sizing(self._ctx, float(headroom), int(min_records)))
+
+    def exchange_stats(self):
+        """(exchanges posted, exchanges that needed a remainder round, next sizes out [left, right], next sizes in)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        o, i = (C.c_int * 2)(), (C.c_int * 2)()
+        _check(self.lib.sph_slab_exchange_stats(self._ctx, C.byref(a), C.byref(b), C.byref(o), C.byref(i)))
+        return a.value, b.value, list(o), list(i)
 
     def empty_records(self, n):
         return self.torch.empty((n, RECORD_WORDS), dtype=self.torch.float32, device=self.device)

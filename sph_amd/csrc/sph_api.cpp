@@ -91,6 +91,10 @@ struct sph_context {
   float* msg_out[2] = {nullptr, nullptr};  // [(xcap + 1) records] message to the left / right neighbour
   float* msg_in[2] = {nullptr, nullptr};   // message from the left / right neighbour
   int cap_out[2] = {0, 0}, cap_in[2] = {0, 0};  // records the next message to / from each neighbour holds (agreed sizes)
+  int posted_out[2] = {0, 0}, posted_in[2] = {0, 0};  // the sizes the exchange in flight was posted with
+  uint64_t remainder_rounds = 0;           // exchanges so far that needed a second round (a message outgrew its size)
+  float size_headroom = 0.25f;             // next message = last true count * (1 + headroom), rounded up to 256 records,
+  int size_min = 1024;                     // at least size_min, at most xcap: identical on every rank
   bool halo_current = false;               // `cur` holds own particles AND the neighbours' records for the next sort
   bool in_flight = false;                  // a begin() has posted an exchange that no end() has completed yet
   uint64_t begun = 0;                      // exchanges posted so far (LOCAL transport: a neighbour must have kept up)
@@ -1049,11 +1053,11 @@ namespace {
 constexpr int kHdr = 1;  // header records in front of a message
 constexpr int kOverlapMinParticles = 4000000;  // sph_slab_set_overlap(ctx, 2): smaller slabs do not split their force pass
 
-int next_capacity(int count, int xcap) {
-  long long want = (long long)count + count / 4 + 1;  // + 25 %
+int next_capacity(const sph_context* c, int count) {
+  long long want = (long long)count + (long long)ceil((double)count * (double)c->size_headroom) + 1;
   want = (want + 255) / 256 * 256;
-  if (want < 1024) want = 1024;
-  return (int)(want > xcap ? xcap : want);
+  if (want < c->size_min) want = c->size_min;
+  return (int)(want > c->xcap ? c->xcap : want);
 }
 
 bool has_face(const sph_context* c, int side, bool next) {
@@ -1085,21 +1089,56 @@ int attach_common(sph_context* c, int rec_capacity) {
   return SPH_OK;
 }
 
-// Posts the exchange of the messages in msg_out (packed and headed on the compute stream, ev_pack recorded behind
-// them) with `cap[side]` records each way.  RCCL: enqueued on the communication stream.  LOCAL: nothing to post - the
-// neighbour fetches the message in its complete_exchange.
-int post_exchange(sph_context* c, const int cap_out[2], const int cap_in[2]) {
-  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+// One round of the transport on the communication stream: towards each neighbour `n_out[k]` words of msg_out[k] from
+// word `off_out[k]` on, from each neighbour `n_in[k]` words into msg_in[k] at word `off_in[k]`.  Both ends of a face
+// pass the same numbers (what one sends the other receives, at the same offset).
+//   RCCL   ncclSend/ncclRecv with ranks rank-1 and rank+1, all inside one group;
+//   LOCAL  the receiver copies out of the neighbour's msg_out (the neighbour's own call moves nothing towards me).
+int transfer_round(sph_context* c, const bool face[2], const size_t off_out[2], const size_t n_out[2],
+                   const size_t off_in[2], const size_t n_in[2], const char* what) {
   if (c->xfer == sph_context::XFER_RCCL) {
     char err[256] = "";
-    const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
+    if (rccl_exchange(c->rccl, c->comm_stream, face[0] ? c->rank - 1 : -1, c->msg_out[0] + off_out[0], n_out[0],
+                      c->msg_in[0] + off_in[0], n_in[0], face[1] ? c->rank + 1 : -1, c->msg_out[1] + off_out[1], n_out[1],
+                      c->msg_in[1] + off_in[1], n_in[1], err, sizeof err))
+      return fail(SPH_ERR_HIP, "%s: %s", what, err);
+    return SPH_OK;
+  }
+  for (int k = 0; k < 2; k++) {
+    if (!face[k] || n_in[k] == 0) continue;
+    HIP_TRY(hipMemcpyAsync(c->msg_in[k] + off_in[k], c->peer[k]->msg_out[1 - k] + off_in[k], n_in[k] * sizeof(float),
+                           hipMemcpyDeviceToDevice, c->comm_stream));
+  }
+  return SPH_OK;
+}
+
+// The header word (true record count) of each received message, to pinned host memory behind the round that brought it.
+int fetch_headers(sph_context* c, const bool face[2]) {
+  for (int k = 0; k < 2; k++)
+    if (face[k])
+      HIP_TRY(hipMemcpyAsync(c->h_counters + 8 + k, c->msg_in[k], sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
+  return SPH_OK;
+}
+
+// Posts the exchange of the messages in msg_out (packed and headed on the compute stream, ev_pack recorded behind
+// them) with cap_out[side] records towards and cap_in[side] records from each neighbour, plus the header record.
+// RCCL: enqueued on the communication stream now.  LOCAL: the neighbour may not have packed yet - every context copies
+// its incoming messages in its complete_exchange, after all contexts of the process have begun.
+int post_exchange(sph_context* c) {
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+  const bool face[2] = {has_face(c, 0, true), has_face(c, 1, true)};
+  for (int k = 0; k < 2; k++) {
+    c->posted_out[k] = c->cap_out[k];
+    c->posted_in[k] = c->cap_in[k];
+  }
+  if (c->xfer == sph_context::XFER_RCCL) {
     const size_t w = SPH_SLAB_RECORD_WORDS;
-    if (rccl_exchange(c->rccl, c->comm_stream, l ? c->rank - 1 : -1, c->msg_out[0], (size_t)(cap_out[0] + kHdr) * w,
-                      c->msg_in[0], (size_t)(cap_in[0] + kHdr) * w, r ? c->rank + 1 : -1, c->msg_out[1],
-                      (size_t)(cap_out[1] + kHdr) * w, c->msg_in[1], (size_t)(cap_in[1] + kHdr) * w, err, sizeof err))
-      return fail(SPH_ERR_HIP, "halo exchange: %s", err);
-    if (l) HIP_TRY(hipMemcpyAsync(c->h_counters + 8, c->msg_in[0], sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
-    if (r) HIP_TRY(hipMemcpyAsync(c->h_counters + 9, c->msg_in[1], sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
+    const size_t zero[2] = {0, 0};
+    const size_t n_out[2] = {(size_t)(c->cap_out[0] + kHdr) * w, (size_t)(c->cap_out[1] + kHdr) * w};
+    const size_t n_in[2] = {(size_t)(c->cap_in[0] + kHdr) * w, (size_t)(c->cap_in[1] + kHdr) * w};
+    int rc = transfer_round(c, face, zero, n_out, zero, n_in, "halo exchange");
+    if (rc == SPH_OK) rc = fetch_headers(c, face);
+    if (rc != SPH_OK) return rc;
   }
   // own count, trash count, what was packed, stray and missed counters: one small copy behind the exchange
   HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, c->comm_stream));
@@ -1109,77 +1148,100 @@ int post_exchange(sph_context* c, const int cap_out[2], const int cap_in[2]) {
   return SPH_OK;
 }
 
+// An exchange that cannot be completed leaves the context without a current halo and with nothing in flight: the
+// caller may upload and start over, but the step that was under way is lost - on every rank, since the neighbours
+// completed their side of it.  Returns `code` for use in a return statement.
+int abandon_exchange(sph_context* c, int code) {
+  (void)hipStreamSynchronize(c->comm_stream);
+  c->in_flight = false;
+  c->halo_current = false;
+  return code;
+}
+
 // Completes the exchange: the ONE host wait of a step (on the communication stream; the compute stream keeps running
 // the interior force pass), then the received records join the particle set behind the own particles.
 // `own_known` >= 0: the own count is that (halo exchange of an uploaded state); < 0: it comes home with the counters.
+// Both transports follow the same size protocol: round one moved posted_out / posted_in records (+ header) whatever
+// the true counts were; the header says how many records the sender really had; what did not fit follows in round two,
+// whose sizes both ends derive from the same two numbers.
 int complete_exchange(sph_context* c, int own_known, bool apply_next) {
-  const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
-  const bool face[2] = {l, r};
-  int n_in[2] = {0, 0};
+  const bool face[2] = {has_face(c, 0, true), has_face(c, 1, true)};
+  const size_t w = SPH_SLAB_RECORD_WORDS;
   if (c->xfer == sph_context::XFER_LOCAL) {
-    // the neighbour's message for me is its msg_out on the side facing me; its header count sits in its counters
     for (int k = 0; k < 2; k++) {
       if (!face[k]) continue;
       sph_context* p = c->peer[k];
-      if (!p || p->begun < c->begun) return fail(SPH_ERR_STATE, "the neighbouring context has not begun this exchange");
+      if (!p || p->begun < c->begun)
+        return abandon_exchange(c, fail(SPH_ERR_STATE, "the neighbouring context has not begun this exchange"));
       if (p->begun > c->begun)
-        return fail(SPH_ERR_STATE, "the neighbouring context has begun its next exchange and overwritten the message: "
-                                   "call begin on all contexts, then end on all of them");
+        return abandon_exchange(c, fail(SPH_ERR_STATE, "the neighbouring context has begun its next exchange and overwritten "
+                                                       "the message: call begin on all contexts, then end on all of them"));
+      if (p->posted_out[1 - k] != c->posted_in[k])
+        return abandon_exchange(c, fail(SPH_ERR_STATE, "message sizes disagree: the neighbour sends %d records, this context "
+                                                       "expects %d", p->posted_out[1 - k], c->posted_in[k]));
+      // the neighbour's ev_pack was recorded in its begin, which (begin on all, then end on all) came before this call
       HIP_TRY(hipStreamWaitEvent(c->comm_stream, p->ev_pack, 0));
-      HIP_TRY(hipMemcpyAsync(c->h_counters + 8 + k, p->d_counters + (1 - k), sizeof(int32_t), hipMemcpyDeviceToHost,
-                             c->comm_stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->comm_stream));
-    for (int k = 0; k < 2; k++) {
-      if (!face[k]) continue;
-      n_in[k] = c->h_counters[8 + k];
-      if (n_in[k] > c->xcap)
-        return fail(SPH_ERR_CAPACITY, "%d halo/migration records exceed the message capacity %d", n_in[k], c->xcap);
-      if (n_in[k] > 0)
-        HIP_TRY(hipMemcpyAsync(c->msg_in[k] + kHdr * SPH_SLAB_RECORD_WORDS,
-                               c->peer[k]->msg_out[1 - k] + kHdr * SPH_SLAB_RECORD_WORDS,
-                               (size_t)n_in[k] * kRecordBytes, hipMemcpyDeviceToDevice, c->comm_stream));
-    }
-    HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+    const size_t zero[2] = {0, 0};
+    const size_t n_in1[2] = {(size_t)(c->posted_in[0] + kHdr) * w, (size_t)(c->posted_in[1] + kHdr) * w};
+    int rc = transfer_round(c, face, zero, zero, zero, n_in1, "halo exchange");
+    if (rc == SPH_OK) rc = fetch_headers(c, face);
+    if (rc != SPH_OK) return abandon_exchange(c, rc);
+    if (hipStreamSynchronize(c->comm_stream) != hipSuccess)
+      return abandon_exchange(c, fail(SPH_ERR_HIP, "waiting for the halo exchange failed"));
   } else {
-    HIP_TRY(hipEventSynchronize(c->ev_comm));
-    int n_out[2] = {c->h_counters[0], c->h_counters[1]};
-    for (int k = 0; k < 2; k++) n_in[k] = face[k] ? c->h_counters[8 + k] : 0;
-    for (int k = 0; k < 2; k++)
-      if (n_in[k] > c->xcap || n_out[k] > c->xcap)
-        return fail(SPH_ERR_CAPACITY, "%d halo/migration records exceed the message capacity %d",
-                    n_in[k] > n_out[k] ? n_in[k] : n_out[k], c->xcap);
-    // remainders of messages that outgrew their agreed size: exact sizes are now known at both ends
-    const int more_out[2] = {face[0] && n_out[0] > c->cap_out[0] ? n_out[0] - c->cap_out[0] : 0,
-                             face[1] && n_out[1] > c->cap_out[1] ? n_out[1] - c->cap_out[1] : 0};
-    const int more_in[2] = {n_in[0] > c->cap_in[0] ? n_in[0] - c->cap_in[0] : 0,
-                            n_in[1] > c->cap_in[1] ? n_in[1] - c->cap_in[1] : 0};
-    if (more_out[0] || more_out[1] || more_in[0] || more_in[1]) {
-      char err[256] = "";
-      const size_t w = SPH_SLAB_RECORD_WORDS;
-      if (rccl_exchange(c->rccl, c->comm_stream, l ? c->rank - 1 : -1, c->msg_out[0] + (size_t)(c->cap_out[0] + kHdr) * w,
-                        (size_t)more_out[0] * w, c->msg_in[0] + (size_t)(c->cap_in[0] + kHdr) * w, (size_t)more_in[0] * w,
-                        r ? c->rank + 1 : -1, c->msg_out[1] + (size_t)(c->cap_out[1] + kHdr) * w, (size_t)more_out[1] * w,
-                        c->msg_in[1] + (size_t)(c->cap_in[1] + kHdr) * w, (size_t)more_in[1] * w, err, sizeof err))
-        return fail(SPH_ERR_HIP, "halo exchange (remainder): %s", err);
-      HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
-    }
-    for (int k = 0; k < 2; k++) {
-      c->cap_out[k] = next_capacity(n_out[k], c->xcap);
-      c->cap_in[k] = next_capacity(n_in[k], c->xcap);
-    }
+    if (hipEventSynchronize(c->ev_comm) != hipSuccess)
+      return abandon_exchange(c, fail(SPH_ERR_HIP, "waiting for the halo exchange failed"));
   }
+  int n_out[2], n_in[2];
+  for (int k = 0; k < 2; k++) {
+    n_out[k] = face[k] ? c->h_counters[k] : 0;
+    n_in[k] = face[k] ? c->h_counters[8 + k] : 0;
+  }
+  // A face that needs more than rec_capacity records fails the run, on BOTH of its ends (they read the same count).
+  // The remainder round is still posted, with the counts clamped the same way at both ends, so that a neighbour on the
+  // other, healthy face is not left waiting for a message that never comes.
+  int over = 0;  // the largest count beyond the capacity (a negative header cannot come from a sender of this library)
+  for (int k = 0; k < 2; k++) {
+    if (n_in[k] < 0) n_in[k] = 0x7fffffff;
+    const int worst = n_in[k] > n_out[k] ? n_in[k] : n_out[k];
+    if (worst > c->xcap && worst > over) over = worst;
+    if (n_in[k] > c->xcap) n_in[k] = c->xcap;
+    if (n_out[k] > c->xcap) n_out[k] = c->xcap;
+  }
+  size_t off_out[2], off_in[2], more_out[2], more_in[2];
+  bool any = false;
+  for (int k = 0; k < 2; k++) {
+    off_out[k] = (size_t)(c->posted_out[k] + kHdr) * w;
+    off_in[k] = (size_t)(c->posted_in[k] + kHdr) * w;
+    more_out[k] = n_out[k] > c->posted_out[k] ? (size_t)(n_out[k] - c->posted_out[k]) * w : 0;
+    more_in[k] = n_in[k] > c->posted_in[k] ? (size_t)(n_in[k] - c->posted_in[k]) * w : 0;
+    any = any || more_out[k] || more_in[k];
+  }
+  if (any) {
+    const int rc = transfer_round(c, face, off_out, more_out, off_in, more_in, "halo exchange (remainder)");
+    if (rc != SPH_OK) return abandon_exchange(c, rc);
+    c->remainder_rounds += 1;
+  }
+  if (any || c->xfer == sph_context::XFER_LOCAL) HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+  for (int k = 0; k < 2; k++) {
+    c->cap_out[k] = next_capacity(c, n_out[k]);
+    c->cap_in[k] = next_capacity(c, n_in[k]);
+  }
+  if (over)
+    return abandon_exchange(c, fail(SPH_ERR_CAPACITY, "%d halo/migration records exceed the message capacity %d", over, c->xcap));
   const int own = own_known >= 0 ? own_known : c->h_counters[2];
   c->lost = c->h_counters[4];
   c->missed = c->h_counters[6];
   if ((long long)own + n_in[0] + n_in[1] > c->n_max)
-    return fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", own, n_in[0] + n_in[1], c->n_max);
+    return abandon_exchange(c, fail(SPH_ERR_CAPACITY, "%d own + %d received particles exceed n_max = %d", own,
+                                    n_in[0] + n_in[1], c->n_max));
   // The records just exchanged were packed for the faces of the NEXT step: those take effect now, before the received
   // records are checked against the local grid (kernels already launched carry their own copy of the old one).
   if (apply_next && c->next_pending) {
     c->next_pending = false;
     const int rc = set_grid(c, &c->params, c->next_lo, c->next_hi);
-    if (rc != SPH_OK) return rc;
+    if (rc != SPH_OK) return abandon_exchange(c, rc);
   }
   // the received records join the set on the compute stream, behind whatever it is still doing
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -1235,6 +1297,51 @@ int sph_slab_attach_local(sph_context* c, sph_context* left, sph_context* right,
   c->peer[1] = right;
   c->xfer = sph_context::XFER_LOCAL;
   return SPH_OK;
+}
+
+int sph_slab_set_message_sizing(sph_context* c, float headroom, int min_records) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (!(headroom >= 0.0f) || headroom > 16.0f || min_records < 1)
+    return fail(SPH_ERR_INVALID, "bad message sizing (headroom %g, minimum %d records)", headroom, min_records);
+  if (c->in_flight) return fail(SPH_ERR_STATE, "an exchange is in flight");
+  c->size_headroom = headroom;
+  c->size_min = min_records;
+  return SPH_OK;
+}
+
+int sph_slab_exchange_stats(const sph_context* c, uint64_t* exchanges, uint64_t* remainder_rounds, int next_out[2],
+                            int next_in[2]) {
+  if (!c) return fail(SPH_ERR_INVALID, "context is NULL");
+  if (exchanges) *exchanges = c->begun;
+  if (remainder_rounds) *remainder_rounds = c->remainder_rounds;
+  for (int k = 0; k < 2; k++) {
+    if (next_out) next_out[k] = c->cap_out[k];
+    if (next_in) next_in[k] = c->cap_in[k];
+  }
+  return SPH_OK;
+}
+
+// The transport's own primitive on this device: the group of ncclSend/ncclRecv the slab exchange posts, with this
+// rank as both neighbours (RCCL matches a rank's sends to itself with its receives from itself, in order).
+int sph_comm_self_exchange(const float* d_send_left, float* d_recv_left, size_t words_left, const float* d_send_right,
+                           float* d_recv_right, size_t words_right) {
+  if ((words_left && (!d_send_left || !d_recv_left)) || (words_right && (!d_send_right || !d_recv_right)))
+    return fail(SPH_ERR_INVALID, "NULL buffer");
+  char err[256] = "";
+  unsigned char id[kRcclIdBytes];
+  if (rccl_unique_id(id, err, sizeof err)) return fail(SPH_ERR_HIP, "%s", err);
+  void* comm = nullptr;
+  if (rccl_comm_create(&comm, id, 0, 1, err, sizeof err)) return fail(SPH_ERR_HIP, "%s", err);
+  hipStream_t stream = nullptr;
+  int rc = SPH_OK;
+  if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) rc = fail(SPH_ERR_HIP, "hipStreamCreate failed");
+  if (rc == SPH_OK && rccl_exchange(comm, stream, 0, d_send_left, words_left, d_recv_left, words_left, 0, d_send_right,
+                                    words_right, d_recv_right, words_right, err, sizeof err))
+    rc = fail(SPH_ERR_HIP, "self exchange: %s", err);
+  if (rc == SPH_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(SPH_ERR_HIP, "self exchange did not complete");
+  if (stream) (void)hipStreamDestroy(stream);
+  rccl_comm_destroy(comm);
+  return rc;
 }
 
 int sph_slab_set_next_columns(sph_context* c, int col_lo, int col_hi) {
@@ -1302,7 +1409,7 @@ int sph_slab_halo_begin(sph_context* c) {
   HIP_TRY(hipEventRecord(c->ev_pack, c->stream));
   // first message of a run: full-size both ways (every rank uses the same rec_capacity)
   c->cap_out[0] = c->cap_out[1] = c->cap_in[0] = c->cap_in[1] = c->xcap;
-  return post_exchange(c, c->cap_out, c->cap_in);
+  return post_exchange(c);
 }
 
 int sph_slab_halo_end(sph_context* c) {
@@ -1353,6 +1460,8 @@ int sph_slab_step_begin(sph_context* c) {
     own_out = nullptr;  // the first launch reports the own and trash counts
   };
   if ((rc = wait_for_readers(c))) return rc;
+  // an empty slab launches nothing that would write the own and trash counts
+  if (n == 0) HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   // Faces first and the interior beside the exchange pays only for slabs of several million particles: three launches
   // of a few hundred thousand particles each leave the chip half empty in their tails (measured on slabs of a million:
   // 0.30 ms of force pass split in three against 0.23 ms in one launch), which is more than a neighbour exchange of
@@ -1373,7 +1482,7 @@ int sph_slab_step_begin(sph_context* c) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_pack, c->stream));
-  if ((rc = post_exchange(c, c->cap_out, c->cap_in))) return rc;
+  if ((rc = post_exchange(c))) return rc;
   // the interior columns, while the records travel
   if (b_lo > a_hi) {
     if (split) force_range(a_hi, b_lo);

@@ -350,15 +350,20 @@ def test_library_exchange_matches_single_context_bitwise(oracle, nslabs, rebalan
         b.close()
 
 
-def test_library_exchange_dam_break_with_fast_front(oracle):
+@pytest.mark.parametrize("headroom,min_records", [(0.25, 1024), (0.0, 1)])
+def test_library_exchange_dam_break_with_fast_front(oracle, headroom, min_records):
     """250k-particle dam break on 4 slabs, 40 steps, rebalanced every other step: the collapse front crosses 2-4
-    columns per step, so the face ranges follow the measured column shift; compared with the single context."""
+    columns per step, so the face ranges follow the measured column shift; compared with the single context.
+    With no headroom in the message sizes the faces outgrow their agreed sizes as the fluid compresses, and the
+    remainder round of the size protocol (the same code for both transports) has to deliver the rest."""
     side = 63
     pos, vel, p = scenes.dam_break(side)
     ids = np.arange(pos.shape[0], dtype=np.int32)
     p.flags = SPH_FLAG_SURFACE_TENSION
     backends, cuts = make_slabs(p, pos, vel, ids, 4, oracle, n_max=ids.size)
     attach_chain(backends, rec_capacity=1 << 17)
+    for b in backends:
+        b.set_message_sizing(headroom, min_records)
     slab.halo_local_slabs(backends)
     with capi.Simulation(p, n_max=ids.size) as single:
         single.upload(pos, vel)
@@ -382,8 +387,84 @@ def test_library_exchange_dam_break_with_fast_front(oracle):
     assert bits_equal(gp, rp) and bits_equal(gv, rv)
     assert all(b.lost() == 0 and b.missed() == 0 for b in backends)
     assert max(loads) < 1.6 * ids.size / 4, f"rebalancing left the slabs unbalanced: {loads}"
+    stats = [b.exchange_stats() for b in backends]
+    assert all(st[0] == 41 for st in stats)  # the halo exchange and one per step
+    rounds = sum(st[1] for st in stats)
+    # faces whose columns move and fluid that compresses outgrow even 25 % of headroom now and then; none at all
+    # must need the second round far more often
+    assert rounds >= (40 if min_records == 1 else 1), f"remainder rounds were expected: {stats}"
+    # what one end will send next is what the other end expects to receive
+    for r in range(3):
+        assert stats[r][2][1] == stats[r + 1][3][0] and stats[r][3][1] == stats[r + 1][2][0]
     for b in backends:
         b.close()
+
+
+def test_disagreeing_message_sizes_are_refused(oracle):
+    """The LOCAL transport moves exactly the agreed number of records per round, as RCCL would: two ends of a face
+    that size their messages differently are told so instead of exchanging the wrong number of bytes."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=12)
+    backends, cuts = make_slabs(p, pos, vel, ids, 2, oracle)
+    attach_chain(backends)
+    backends[0].set_message_sizing(0.25, 1024)
+    backends[1].set_message_sizing(0.25, 4096)
+    slab.halo_local_slabs(backends)  # first messages are full-size at both ends
+    for b in backends:
+        b.step_begin()
+    with pytest.raises(capi.SphError) as e:
+        backends[0].step_end()
+    assert e.value.code == 5 and "sizes disagree" in str(e.value)  # SPH_ERR_STATE
+    with pytest.raises(capi.SphError):
+        backends[0].step_end()  # nothing is in flight any more: the context can be re-uploaded, not resumed
+    for b in backends:
+        b.close()
+
+
+def test_slab_emptied_between_steps_reports_no_particles(oracle):
+    """A slab that held particles, is re-uploaded empty and takes an overlapped step must come back empty: the own
+    count of the earlier step must not return with the step's counters."""
+    p = default_params(flags=DBG)
+    pos, vel, ids = moving_block(n_side=10)
+    gn = capi.global_cells(p)
+    b = capi.SlabSimulation(p, n_max=ids.size, col_lo=0, col_hi=gn)
+    b.attach_local(None, None, 4096)
+    b.upload(pos, vel, ids)
+    b.halo_begin(); b.halo_end()
+    b.step_begin(); b.step_end()
+    assert b.n == ids.size
+    b.upload(pos[:0], vel[:0], ids[:0])
+    b.halo_begin(); b.halo_end()
+    b.step_begin(); b.step_end()
+    assert b.n == 0 and b.last_own() == 0
+    b.close()
+
+
+def test_rccl_send_recv_on_one_gpu():
+    """Real ncclSend / ncclRecv through the function the slab exchange posts its messages with (one group: send left,
+    receive left, send right, receive right), this rank being both of its neighbours: messages of unequal length, a
+    header word in front as the exchange has it, every byte and both headers checked, receive buffers pre-filled."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n_left, n_right = 7 * 1025, 7 * 3333  # header record + 1024 / 3332 records
+    send_left = torch.rand(n_left, generator=g).to(dev)
+    send_right = torch.rand(n_right, generator=g).to(dev)
+    send_left[0] = torch.tensor([1024], dtype=torch.int32).view(torch.float32)[0]   # true counts, bit-cast
+    send_right[0] = torch.tensor([3332], dtype=torch.int32).view(torch.float32)[0]
+    recv_left = torch.full((n_left,), -1.0, device=dev)
+    recv_right = torch.full((n_right,), -1.0, device=dev)
+    torch.cuda.synchronize()
+    capi.comm_self_exchange(send_left, recv_left, send_right, recv_right)
+    assert torch.equal(recv_left.view(torch.int32), send_left.view(torch.int32))
+    assert torch.equal(recv_right.view(torch.int32), send_right.view(torch.int32))
+    assert int(recv_left[:1].view(torch.int32)[0]) == 1024 and int(recv_right[:1].view(torch.int32)[0]) == 3332
+    # one-sided round (a remainder that only the right face needs): nothing is posted for the left face
+    recv_right.fill_(-1.0)
+    torch.cuda.synchronize()
+    capi.comm_self_exchange(send_left[:0], recv_left[:0], send_right[7:7 * 100], recv_right[7:7 * 100])
+    assert torch.equal(recv_right[7:7 * 100].view(torch.int32), send_right[7:7 * 100].view(torch.int32))
+    assert float(recv_right[0]) == -1.0 and float(recv_right[7 * 100]) == -1.0
 
 
 @pytest.mark.parametrize("by", ["count", "work"])
