@@ -5,9 +5,12 @@ reference compute/compute.cpp:120-320) on N MI355X GPUs of one node.
     python bench.py --gpus N --steps K --warmup W
 
 N = 1 : the 1M-particle dam-break block (100^3 jittered lattice in the corner of a tank twice
-        its width), fp32, inputs resident in HBM before the timed region.
-N > 1 : launched by torch.distributed.run, one rank per GPU; the dam-break block grows along x
-        with N (weak scaling: per-GPU particle count fixed) and is slab-decomposed along x.
+        its width), fp32, inputs resident in HBM before the timed region; the 16.8M-particle uniform
+        cube and the 8M-particle dam break (the per-GPU share of the 64M one) follow as extra_configs.
+N > 1 : one rank per GPU (launched by torch.distributed.run, or by this script itself when it is
+        started plainly: the parent makes no GPU call and starts the ranks as children); the block
+        holds 200^3 particles per GPU by default - 8 GPUs run the 64M-particle dam break - and is
+        slab-decomposed along x (sph_amd/slab_bench.py).
 
 The dam break is not a steady state: a step costs 0.25 ms while the block is still at rest density
 (13 neighbours per particle) and more than twice that at peak compression (53 neighbours).  So
@@ -34,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 from sph_amd import capi, scenes  # noqa: E402
 from sph_amd.params import SPH_FLAG_SURFACE_TENSION  # noqa: E402
+from sph_amd.slab_bench import DEFAULT_SIDE_PER_GPU, peak_preroll  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
 
@@ -52,9 +56,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--preroll", type=int, default=60,
-                    help="untimed steps before the warm-up: the phase of the collapse the timed window starts in")
-    ap.add_argument("--side", type=int, default=100, help="dam-break block is side^3 particles per GPU")
+    ap.add_argument("--preroll", type=int, default=None,
+                    help="untimed steps before the warm-up: the phase of the collapse the timed window starts in "
+                         "(default: peak compression, 60 steps at side 100, scaled with the square root of the side)")
+    ap.add_argument("--side", type=int, default=None,
+                    help="the block is side^3 particles per GPU (default 100 on one GPU, 200 per GPU on several)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="single GPU: skip the uniform-cube and 8M dam-break lines and the reference-arithmetic figure")
     ap.add_argument("--workload", default="dam_break", choices=["dam_break", "uniform_cube", "sloshing"])
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,12 +78,16 @@ def parse_args():
 CPU_SAMPLE_SIDES = (14, 27, 37)  # 2 744, 19 683 and 50 653 particles: the sizes the all-pairs fit is made on
 
 
-def cpu_baseline(args):
+def cpu_baseline(n_bench):
     """The reference algorithm (all-pairs, O(N^2)) on host cores, on bounded samples of the workload: side^3
     sub-blocks of the dam-break field at three sizes, a t = c*N^2 fit through them, and its value at the
     benchmark's particle count."""
     from oracle import Oracle, Ref  # checker only: timed here as the reported CPU baseline
     orc = Oracle()
+    # A launcher may have pinned the ranks to one OpenMP thread each (torch.distributed.run does when the variable is
+    # unset): the baseline is timed on this box's share of host cores, 16 per GPU at most.
+    if orc.num_threads() < 2:
+        orc.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     threads = orc.num_threads()
     kind = "reference" if Ref.available() else "port"
     points = []
@@ -105,7 +117,6 @@ def cpu_baseline(args):
     ts = np.array([q[1] for q in points], np.float64)
     slope = float(np.polyfit(np.log(ns[1:]), np.log(ts[1:]), 1)[0])  # measured exponent between the two large sizes
     c = float((ts * ns ** 2).sum() / (ns ** 4).sum())               # least-squares t = c N^2
-    n_bench = args.side ** 3
     t_bench = c * float(n_bench) ** 2
     return {
         "value": n_bench / t_bench,
@@ -228,13 +239,51 @@ def run_single(args):
     return dict(n=n, dt=dt, timings=tm, breakdown=breakdown, workload=workload, params=p, step_ms=step_ms, rest=rest)
 
 
+def generated_window(scene, side, preroll, warmup, steps, reference_arith=False):
+    """One more configuration on the same GPU: the scene is generated in HBM, advanced to its window, and the timed
+    steps bracket the force pass with events (as the main window does).  Returns a bench-line-shaped dict."""
+    from sph_amd.params import SPH_FLAG_REFERENCE_ARITH, default_params
+    p = scenes.dam_break_params(side) if scene == "dam_break" else default_params(tank_size=side * scenes.REST_SPACING)
+    p.flags = SPH_FLAG_SURFACE_TENSION | (SPH_FLAG_REFERENCE_ARITH if reference_arith else 0)
+    n = side ** 3
+    with capi.Simulation(p, n_max=n, device=int(os.environ.get("LOCAL_RANK", "0"))) as sim:
+        sim.fill_lattice(side, side, side)
+        sim.step(preroll + warmup)
+        sim.sync()
+        sim.enable_timing(2)
+        sim.reset_timings()
+        t0 = time.perf_counter()
+        ms = sim.step_profile(steps)
+        dt = time.perf_counter() - t0
+        tm = sim.timings()
+    force_ms = tm["force_ms"] / steps
+    achieved = BYTES_PER_PARTICLE["force"] * n / (force_ms * 1e-3) / 1e9
+    return {"workload": f"{scene}_{side}^3", "particles": n, "tank_size": float(p.tank_size),
+            "arithmetic": "reference (double coefficient products, IEEE division and square root)" if reference_arith
+                          else "fast",
+            "phase": {"preroll_steps": preroll, "timed_steps": [preroll + warmup, preroll + warmup + steps]},
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "particle-updates/s",
+            "ms_per_step_device": {"min": float(ms.min()), "mean": float(ms.mean()), "max": float(ms.max())},
+            "roofline": {"bound": "hbm", "kernel": "k_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_particle": BYTES_PER_PARTICLE["force"], "avg_launch_ms": force_ms}}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: this process makes no GPU call; the ranks are fresh children under torch.distributed.run
+        from sph_amd import slab_bench
+        sys.exit(slab_bench.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.gpus > 1 or world > 1 or args.force_slab:
         from sph_amd import slab_bench
         return slab_bench.main(args)
+    if args.side is None:
+        args.side = 100
+    if args.preroll is None:
+        args.preroll = peak_preroll(args.side) if args.workload != "uniform_cube" else 20
 
     r = run_single(args)
     n, dt, tm = r["n"], r["dt"], r["timings"]
@@ -259,7 +308,7 @@ def main():
                    "arithmetic": "fast (fp32 coefficients, refined rcp/rsq); neighbour sets exact"},
         "phase": {"preroll_steps": args.preroll, "timed_steps": [first, first + steps],
                   "description": ("peak compression of the dam-break collapse (~50 neighbours per particle)"
-                                  if args.workload == "dam_break" and 40 <= args.preroll <= 90 else
+                                  if args.workload == "dam_break" and args.preroll == peak_preroll(args.side) else
                                   f"{args.preroll} steps after the initial state")},
     }
     if r["step_ms"] is not None and len(r["step_ms"]):
@@ -295,8 +344,18 @@ def main():
         if prof and prof.get("issue_side"):
             # what actually bounds the gathering sweeps, from counters of this same window (see profiles/)
             out["issue_side"] = prof["issue_side"]
+    if not args.no_extra_configs and not args.no_events and args.workload == "dam_break":
+        out["extra_configs"] = [
+            # steady-state neighbour search + force load: the 16.8M-particle cube that fills its tank
+            generated_window("uniform_cube", 256, 20, 5, 20),
+            # the per-GPU share of the 64M-particle dam break: the denominator of the multi-GPU line's efficiency
+            generated_window("dam_break", DEFAULT_SIDE_PER_GPU, peak_preroll(DEFAULT_SIDE_PER_GPU), 5, 20),
+        ]
+        ref = generated_window("dam_break", args.side, args.preroll, args.warmup, min(steps, 20), reference_arith=True)
+        out["reference_arithmetic_extra"] = {k: ref[k] for k in ("workload", "arithmetic", "phase", "steps", "ms_per_step",
+                                                                 "value", "unit", "roofline")}
     if not args.no_cpu_baseline and rank == 0:
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline(n)
         if args.workload == "dam_break":
             out["cpu_grid_twin"] = cpu_grid_twin(args)
     print(json.dumps(out))

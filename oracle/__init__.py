@@ -53,6 +53,8 @@ class Oracle:
         L.sph_oracle_step_grid.argtypes = [P, _F, _F, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
         L.sph_oracle_num_threads.restype = C.c_int
+        L.sph_oracle_set_num_threads.argtypes = [C.c_int]
+        L.sph_oracle_set_num_threads.restype = None
 
     def consts(self, params):
         k = OracleConsts()
@@ -100,6 +102,10 @@ class Oracle:
 
     def num_threads(self):
         return int(self.lib.sph_oracle_num_threads())
+
+    def set_num_threads(self, n):
+        """OpenMP threads of this process from now on (the reference build shares the runtime)."""
+        self.lib.sph_oracle_set_num_threads(int(n))
 
 
 class Ref:

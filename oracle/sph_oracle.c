@@ -435,3 +435,12 @@ int sph_oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+/* The OpenMP runtime is shared by everything in the process that links it (the reference build included). */
+void sph_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

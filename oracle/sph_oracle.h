@@ -75,6 +75,7 @@ void sph_oracle_step_grid(const sph_params* p, float* pos, float* vel, const int
                           int32_t* ncount_out);
 
 int sph_oracle_num_threads(void);
+void sph_oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,16 @@ p.flags = SPH_FLAG_SURFACE_TENSION | (SPH_FLAG_REFERENCE_ARITH if reference else
 n = side ** 3
 with capi.Simulation(p, n_max=n) as sim:
     sim.fill_lattice(side, side, side)
-    sim.step(first)
+    sim.step(max(0, first - 1))
+    if first > 0:  # neighbour counts of the step right before the window
+        q = p.copy()
+        q.flags |= SPH_FLAG_KEEP_DEBUG
+        sim.set_params(q)
+        sim.step(1)
+        nc0 = sim.download_debug(force=False)[2]
+        sim.set_params(p)
+    else:
+        nc0 = None
     sim.sync()
     sim.enable_timing(True)
     sim.reset_timings()
@@ -31,6 +40,7 @@ per = {k[:-3]: v / steps for k, v in tm.items() if k.endswith("_ms")}
 print(json.dumps({"scene": scene, "side": side, "particles": n, "grid": list(dims), "window": [first, first + steps],
                   "arithmetic": "reference" if reference else "fast",
                   "ms_per_step": float(np.mean(ms)), "particle_updates_per_s": n / (float(np.mean(ms)) * 1e-3),
+                  "mean_neighbours_before": float(nc0.mean()) if nc0 is not None else None,
                   "mean_neighbours": float(nc.mean()), "max_neighbours": int(nc.max()),
                   "kernel_ms_per_step": {k: round(v, 4) for k, v in per.items()},
                   "kernel_ms_per_million": {k: round(v / (n / 1e6), 4) for k, v in per.items()},

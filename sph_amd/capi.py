@@ -393,6 +393,11 @@ class SlabSimulation:
         _check(self.lib.sph_set_params(self._ctx, C.byref(params)))
         self.params = params.copy()
 
+    def set_gravity(self, g):
+        p = self.params.copy()
+        p.gravity[0], p.gravity[1], p.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+        self.set_params(p)
+
     def lost(self):
         v = C.c_int64()
         _check(self.lib.sph_slab_lost(self._ctx, C.byref(v)))
