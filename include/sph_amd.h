@@ -357,7 +357,10 @@ int sph_slab_step_begin(sph_context* ctx);
 int sph_slab_step_end(sph_context* ctx);
 int sph_slab_exchange_step(sph_context* ctx); /* begin + end: one context per process */
 /* Faces for the records of the next sph_slab_step_begin and for every step after it (load balancing): all ranks
- * must call it between the same two steps; a face moves by at most one column per step. */
+ * must call it between the same two steps; a face moves by at most SPH_SLAB_MAX_FACE_MOVE columns per step (the face
+ * ranges of that step widen by as many columns: a front that crosses three columns per step can be followed at its
+ * own pace). */
+#define SPH_SLAB_MAX_FACE_MOVE 8
 int sph_slab_set_next_columns(sph_context* ctx, int col_lo, int col_hi);
 int sph_slab_set_face_shift(sph_context* ctx, float columns);
 /* How sph_slab_step_begin orders its force pass: 1 = face columns first, interior columns while the records travel;

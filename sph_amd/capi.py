@@ -97,6 +97,7 @@ NOALLOC_MAX_PARTICLES = 32768  # SPH_NOALLOC_MAX_PARTICLES
 NOALLOC_MAX_CELLS = 262144     # SPH_NOALLOC_MAX_CELLS
 RECORD_WORDS = 7      # SPH_SLAB_RECORD_WORDS: x, y, z, vx, vy, vz, id
 MIN_SLAB_COLUMNS = 4  # SPH_SLAB_MIN_COLUMNS
+MAX_FACE_MOVE = 8     # SPH_SLAB_MAX_FACE_MOVE
 
 _lib = None
 

@@ -1351,8 +1351,8 @@ int sph_slab_set_next_columns(sph_context* c, int col_lo, int col_hi) {
     return fail(SPH_ERR_INVALID, "slab columns [%d, %d) invalid", col_lo, col_hi);
   if (col_hi - col_lo > c->cols_capacity)
     return fail(SPH_ERR_CAPACITY, "%d columns exceed cols_capacity = %d", col_hi - col_lo, c->cols_capacity);
-  if (abs(col_lo - c->col_lo) > 1 || abs(col_hi - c->col_hi) > 1)
-    return fail(SPH_ERR_INVALID, "a face may move by at most one column per step");
+  if (abs(col_lo - c->col_lo) > SPH_SLAB_MAX_FACE_MOVE || abs(col_hi - c->col_hi) > SPH_SLAB_MAX_FACE_MOVE)
+    return fail(SPH_ERR_INVALID, "a face may move by at most %d columns per step", SPH_SLAB_MAX_FACE_MOVE);
   if (c->in_flight)
     return fail(SPH_ERR_STATE, "an exchange is in flight: its records were packed for the faces as they stood at sph_slab_step_begin");
   c->next_lo = col_lo;
@@ -1444,7 +1444,9 @@ int sph_slab_step_begin(sph_context* c) {
   // face ranges (local columns): wide enough that whatever can reach the neighbour's halo within this step, and the
   // column a face may move by, starts inside them
   const bool l = has_face(c, 0, true), r = has_face(c, 1, true);
-  const int width = 3 + (int)ceilf(c->face_shift) + (c->next_pending ? 1 : 0);
+  // ... plus the columns a face is about to move by: what the neighbour gains must have its new state first as well
+  const int move_lo = c->next_pending ? abs(c->next_lo - c->col_lo) : 0, move_hi = c->next_pending ? abs(c->next_hi - c->col_hi) : 0;
+  const int width = 3 + (int)ceilf(c->face_shift) + (move_lo > move_hi ? move_lo : move_hi);
   const DevParams& G = c->dev;
   const int a_lo = G.own_lo, a_hi = l ? (G.own_lo + width < G.own_hi ? G.own_lo + width : G.own_hi) : G.own_lo;
   const int b_hi = G.own_hi, b_lo = r ? (G.own_hi - width > a_hi ? G.own_hi - width : a_hi) : G.own_hi;

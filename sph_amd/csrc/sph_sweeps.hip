@@ -194,22 +194,28 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
     const int m = qe - q < kAhead ? qe - q : kAhead;
     // Always fetch kAhead consecutive slots from one base address: past the end of the run they belong to the
     // next cell or to the array's padding, and their outcomes are masked off below.
-    // kAhead = 4 packed positions are 48 bytes: three 16-byte loads (dword-aligned, as global loads may be)
-    const Quad* base = reinterpret_cast<const Quad*>(st.pos3 + 3 * (size_t)(shift + q));
+    // kAhead = 4 packed positions are 48 bytes: three 16-byte loads (dword-aligned, as global loads may be), addressed
+    // by a 32-bit byte offset from the array's base (a context holds far fewer than 2^32 / 12 particles)
+    const Quad* base = reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(st.pos3) + (unsigned)(shift + q) * 12u);
     const Quad w0 = base[0], w1 = base[1], w2 = base[2];
     float4 cand[kAhead];
     cand[0] = make_float4(w0.a, w0.b, w0.c, 0.0f);
     cand[1] = make_float4(w0.d, w1.a, w1.b, 0.0f);
     cand[2] = make_float4(w1.c, w1.d, w2.a, 0.0f);
     cand[3] = make_float4(w2.b, w2.c, w2.d, 0.0f);
+    float r2[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) r2[u] = dist2_to(pi, cand[u], dx, dy, dz);
+    // outcomes shifted in from the last candidate to the first, one add-with-carry each: bit u <=> candidate u passes
     unsigned bits = 0;
 #pragma unroll
-    for (int u = 0; u < kAhead; u++) {
-      const float r2 = dist2_to(pi, cand[u], dx, dy, dz);
-      const bool hit = WITH_DENSITY ? (r2 <= P.r2_max && u < m) : r2 <= P.r2_max;
-      bits |= (hit ? 1u : 0u) << u;
-      if (WITH_DENSITY) {
-        const float d = hit ? P.h2 - r2 : 0.0f;
+    for (int u = kAhead - 1; u >= 0; u--) bits = bits + bits + (r2[u] <= P.r2_max ? 1u : 0u);
+    if (WITH_DENSITY) {
+      // (h2 - r2) clamped at 0 in the subtraction itself: a candidate beyond h adds nothing, and one beyond the end of
+      // the run is kept out by the limit it is compared with
+#pragma unroll
+      for (int u = 0; u < kAhead; u++) {
+        const float d = __builtin_amdgcn_fmed3f(P.h2 - (u < m ? r2[u] : P.h2), 0.0f, 1.0f);
         sum = __builtin_fmaf(d * d, d, sum);
       }
     }

@@ -19,7 +19,7 @@ This module contains no physics: `backend` is sph_amd.capi.SlabSimulation (HIP) 
 """
 import numpy as np
 
-from .capi import MIN_SLAB_COLUMNS, RECORD_WORDS  # noqa: F401
+from .capi import MAX_FACE_MOVE, MIN_SLAB_COLUMNS, RECORD_WORDS  # noqa: F401
 
 
 # ---- cut planes ---------------------------------------------------------------------------------------
@@ -50,14 +50,20 @@ def partition_columns(hist, nranks, min_cols=MIN_SLAB_COLUMNS):
     return cuts
 
 
-def min_columns_for_shift(max_shift_columns):
+def min_columns_for_shift(max_shift_columns, face_move=1):
     """Narrowest slab that one exchange per step between direct neighbours can serve.
 
     A particle that crosses D columns in a step must still land in its old owner's own or neighbouring
-    slab (+- 2 ghost columns): every slab has to be ceil(D) + 2 columns wide, + 1 while the cut planes
-    themselves move by a column.
+    slab (+- 2 ghost columns): every slab has to be ceil(D) + 2 columns wide, + the columns the cut planes
+    themselves move by in a step.
     """
-    return max(MIN_SLAB_COLUMNS, int(np.ceil(max_shift_columns)) + 3)
+    return max(MIN_SLAB_COLUMNS, int(np.ceil(max_shift_columns)) + 2 + int(face_move))
+
+
+def face_move_for_shift(max_shift_columns):
+    """Columns a cut plane may travel per step: as many as the fastest particle crosses, so that the planes can follow a
+    front (a dam-break front runs at 2-4 columns per step), within what one exchange covers."""
+    return int(min(MAX_FACE_MOVE, max(1, np.ceil(max_shift_columns))))
 
 
 def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
@@ -342,9 +348,11 @@ def step_local_slabs_overlapped(backends):
         b.step_end()
 
 
-def rebalance_next_local_slabs(backends, cuts, by="work"):
+def rebalance_next_local_slabs(backends, cuts, by="work", stats=None, max_move=None):
     """Load balancing for the library-driven exchange: the new cuts apply to the records of the next step.
-    by="work" balances the sum of (9 + neighbours) per slab - what a step costs - instead of the particle count."""
+    by="work" balances the sum of (9 + neighbours) per slab - what a step costs - instead of the particle count.
+    `stats`, a dict, receives the load per slab under the cuts as they stood (key "load") and the column shift.
+    max_move: columns a face may travel in this call (default: as many as the fastest particle crosses per step)."""
     hist = np.zeros(cuts[-1], np.int64)
     shift = 0.0
     for r, b in enumerate(backends):
@@ -352,7 +360,11 @@ def rebalance_next_local_slabs(backends, cuts, by="work"):
         c = work if by == "work" else counts
         hist[first:first + len(c)] = c
         shift = max(shift, s)
-    new = rebalance_cuts(cuts, hist, min_cols=min_columns_for_shift(shift))
+    if stats is not None:
+        stats["load"] = [int(hist[cuts[r]:cuts[r + 1]].sum()) for r in range(len(backends))]
+        stats["shift"] = shift
+    move = face_move_for_shift(shift) if max_move is None else max_move
+    new = rebalance_cuts(cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move))
     for r, b in enumerate(backends):
         b.set_face_shift(shift)
         b.set_next_columns(new[r], new[r + 1])
@@ -422,8 +434,10 @@ class LibraryRunner:
         full = full.cpu().numpy()
         ncols = self.cuts[-1]
         # one column of margin: the shift was measured up to rebalance_every + 1 steps before the faces it sizes are used
-        hist, shift = full[:ncols], float(full[ncols:].max()) / 1024.0 + 1.0
-        new = rebalance_cuts(self.cuts, hist, min_cols=min_columns_for_shift(shift))
+        raw = float(full[ncols:].max()) / 1024.0
+        hist, shift = full[:ncols], raw + 1.0
+        move = face_move_for_shift(raw)
+        new = rebalance_cuts(self.cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move))
         b.set_face_shift(shift)
         b.set_next_columns(new[self.rank], new[self.rank + 1])
         self.cuts = new

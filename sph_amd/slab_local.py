@@ -20,7 +20,7 @@ from . import capi, scenes, slab
 from .params import SPH_FLAG_SURFACE_TENSION
 
 
-def build(scene, side, nslabs, rec_factor=64):
+def build(scene, side, nslabs, rec_factor=64, n_max_factor=1.3):
     """K slab contexts holding a side^3 jittered block in the corner of a tank twice its width, generated in HBM."""
     p = scenes.dam_break_params(side)
     p.flags = SPH_FLAG_SURFACE_TENSION
@@ -31,8 +31,10 @@ def build(scene, side, nslabs, rec_factor=64):
     hist = np.bincount(plane_col, minlength=gn) * side * side
     cuts = slab.partition_columns(hist, nslabs)
     n_total = side ** 3
-    # own particles (+30 % for imbalance between rebalances) + four ghost columns of ~1.5 lattice planes each
-    n_max = int(1.3 * n_total / nslabs) + 8 * side * side
+    # own particles (+30 % for imbalance between rebalances; cut planes steered by work give a slab of uncompressed
+    # fluid up to 2.7 times the particles of a compressed one: long runs ask for more) + four ghost columns of ~1.5
+    # lattice planes each
+    n_max = int(n_max_factor * n_total / nslabs) + 8 * side * side
     backends = []
     for r in range(nslabs):
         mine = np.nonzero((plane_col >= cuts[r]) & (plane_col < cuts[r + 1]))[0]
@@ -49,14 +51,14 @@ def build(scene, side, nslabs, rec_factor=64):
     return p, backends, cuts
 
 
-def run(scene, side, nslabs, steps, rebalance_every=2, check=True):
-    p, backends, cuts = build(scene, side, nslabs)
+def run(scene, side, nslabs, steps, rebalance_every=2, check=True, n_max_factor=1.3):
+    p, backends, cuts = build(scene, side, nslabs, n_max_factor=n_max_factor)
     n_total = side ** 3
     slab.halo_local_slabs(backends)
     for b in backends:
         b.sync()
     t0 = time.perf_counter()
-    worst = 1.0
+    worst, worst_work, work_trace = 1.0, 1.0, []
     for s in range(steps):
         if scene == "sloshing":  # the reference's mutable a_gravity (compute.cpp:12), turned every step
             g = scenes.sloshing_gravity(s)
@@ -66,9 +68,13 @@ def run(scene, side, nslabs, steps, rebalance_every=2, check=True):
                 b.set_params(q)
         slab.step_local_slabs_overlapped(backends)
         if rebalance_every and s % rebalance_every == rebalance_every - 1:
-            cuts = slab.rebalance_next_local_slabs(backends, cuts)
+            st = {}
+            cuts = slab.rebalance_next_local_slabs(backends, cuts, stats=st)
             own = [b.last_own() for b in backends]
             worst = max(worst, max(own) * nslabs / float(sum(own)))
+            w = max(st["load"]) * nslabs / float(sum(st["load"]))  # what the cut planes steer: sum of (9 + neighbours)
+            worst_work = max(worst_work, w)
+            work_trace.append(round(w, 3))
     for b in backends:
         b.sync()
     dt = time.perf_counter() - t0
@@ -76,7 +82,8 @@ def run(scene, side, nslabs, steps, rebalance_every=2, check=True):
     out = {"scene": scene, "particles": n_total, "slabs": nslabs, "steps": steps, "ms_per_step": dt / steps * 1e3,
            "particle_updates_per_s": n_total * steps / dt, "own_particles": own,
            "lost": sum(b.lost() for b in backends), "missed": sum(b.missed() for b in backends),
-           "worst_imbalance": worst, "cuts": [int(c) for c in cuts]}
+           "worst_imbalance": worst, "worst_work_imbalance": worst_work,
+           "work_imbalance_every_20th_rebalance": work_trace[::20], "cuts": [int(c) for c in cuts]}
     if check:
         lo, hi = np.inf, -np.inf
         finite = True

@@ -42,6 +42,52 @@ def test_no_alloc_entry_point_matches_update_particles():
     assert bits_equal(gp, hp) and bits_equal(gv, hv)
 
 
+def test_no_alloc_entry_point_against_the_oracle(oracle):
+    """One step through the no-allocation entry point against the CPU restatement of the reference's algorithm
+    (all-pairs, the reference's own summation order): the default arithmetic's one-step bound of 1e-5 on positions
+    and velocities, scaled by the field maximum."""
+    torch = pytest.importorskip("torch")
+    from conftest import max_rel
+    p = default_params(flags=SPH_FLAG_SURFACE_TENSION)
+    pos, vel = scenes.random_block(3000, seed=5)  # the reference's default scene size (main.cpp:8)
+    po, vo = pos.copy(), vel.copy()
+    oracle.step_allpairs(p, po, vo)
+    dp, dv = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+    capi.update_particles_noalloc(dp.data_ptr(), dv.data_ptr(), 3000, p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert max_rel(dp.cpu().numpy(), po) <= 1e-5 and max_rel(dv.cpu().numpy(), vo) <= 1e-5
+
+
+def test_no_alloc_entry_point_allocates_nothing_and_can_be_captured():
+    """What the entry point is for: device memory in use does not change across calls (first call on the device
+    included: its scratch is a static array of the library), and a call can be recorded into a HIP graph and replayed -
+    something no allocating call survives - with the bits of the direct calls."""
+    torch = pytest.importorskip("torch")
+    p = default_params(flags=SPH_FLAG_SURFACE_TENSION)
+    pos, vel = scenes.random_block(5000, seed=21)
+    dp, dv = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+    gp, gv = dp.clone(), dv.clone()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        capi.update_particles_noalloc(dp.data_ptr(), dv.data_ptr(), 5000, p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "the call changed the amount of device memory in use"
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        capi.update_particles_noalloc(gp.data_ptr(), gv.data_ptr(), 5000, p, side.cuda_stream)
+        graph.capture_end()
+    torch.cuda.synchronize()
+    # capturing executes nothing: gp, gv still hold the initial state; three replays = the three direct calls
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert bits_equal(gp.cpu().numpy(), dp.cpu().numpy()) and bits_equal(gv.cpu().numpy(), dv.cpu().numpy())
+
+
 def test_no_alloc_entry_point_rejects_what_does_not_fit():
     torch = pytest.importorskip("torch")
     p = default_params(flags=SPH_FLAG_SURFACE_TENSION)
