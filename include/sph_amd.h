@@ -183,6 +183,17 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
                          int num_particles);
 
 /*
+ * The one-call form moves 48 bytes per particle over PCIe every step (the reference's contract: host arrays valid on
+ * return, render.cpp:240-253).  From ordinary (pageable) memory those transfers go through the runtime's staging
+ * buffers; from page-locked memory they are direct DMA.  sph_host_register page-locks a range the caller allocated
+ * (malloc, new[], ...) in place - the pointer stays what it was, free() still works on it at process end - and
+ * sph_host_unregister undoes it; unregister before freeing memory that the process goes on to reuse.  Registering a
+ * range twice is not an error.  The drop-in initParticles registers the two arrays it hands out.
+ */
+int sph_host_register(void* host_ptr, size_t bytes);
+int sph_host_unregister(void* host_ptr);
+
+/*
  * The same step for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  (No counterpart in the reference, whose updateParticles mallocs
  * its temporaries on every call, compute.cpp:122,128.)  One updateParticles on DEVICE arrays of

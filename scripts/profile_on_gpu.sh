@@ -5,7 +5,7 @@
 # usage: scripts/profile_on_gpu.sh <tag>      outputs under gpurun_out/prof_<tag>_{stats,fetch,write,sq,mix,ta}
 set -e
 tag=$1
-ARGS="--steps 20 --warmup 5 --preroll 60 --no-cpu-baseline"
+ARGS="--steps 20 --warmup 5 --preroll 60 --no-cpu-baseline --no-extra-configs"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_${tag}_*
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- \

@@ -48,6 +48,8 @@ _SIGNATURES = [
     ("sph_get_timings", C.c_int, [_CTX, C.POINTER(SphTimings)]),
     ("sph_reset_timings", C.c_int, [_CTX]),
     ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_host_register", C.c_int, [C.c_void_p, C.c_size_t]),
+    ("sph_host_unregister", C.c_int, [C.c_void_p]),
     ("sph_update_particles_noalloc", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("sph_fill_lattice", C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64,
                                    C.c_void_p]),
@@ -524,6 +526,15 @@ def update_particles(pos, vel, params=None):
     assert pos.dtype == np.float32 and vel.dtype == np.float32 and pos.flags.c_contiguous and vel.flags.c_contiguous
     _check(lib.sph_update_particles(C.byref(params) if params is not None else None, pos.ctypes.data,
                                     vel.ctypes.data, pos.size // 3))
+
+
+def host_register(array):
+    """Page-lock a numpy array in place (direct DMA for uploads and downloads from it)."""
+    _check(load().sph_host_register(C.c_void_p(array.ctypes.data), array.nbytes))
+
+
+def host_unregister(array):
+    _check(load().sph_host_unregister(C.c_void_p(array.ctypes.data)))
 
 
 def update_particles_noalloc(d_pos_ptr, d_vel_ptr, n, params=None, stream_ptr=None):

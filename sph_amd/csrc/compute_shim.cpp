@@ -61,6 +61,13 @@ void initParticles(float** particles, float** velocities, int numParticles) {
   *particles = static_cast<float*>(std::malloc((count ? count : 1) * sizeof(float)));
   *velocities = static_cast<float*>(std::malloc((count ? count : 1) * sizeof(float)));
   if (!*particles || !*velocities) die("initParticles allocation");
+  // The caller keeps these two arrays for the whole run and hands them back every step (main.cpp:27-35): page-locked,
+  // the 24 bytes per particle each way are direct DMA.  Plain malloc memory before and after (main.cpp:37 frees one of
+  // them with free()); a refusal (no device yet, locked-memory limit) only costs speed.
+  if (count * sizeof(float) >= (size_t)1 << 18) {
+    (void)sph_host_register(*particles, count * sizeof(float));
+    (void)sph_host_register(*velocities, count * sizeof(float));
+  }
   unsigned long long seed = (unsigned long long)std::time(nullptr);
   if (const char* e = std::getenv("SPH_AMD_SEED")) seed = std::strtoull(e, nullptr, 10);
   sph_params p = params_from_globals();

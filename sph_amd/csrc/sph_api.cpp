@@ -1574,6 +1574,50 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
   return sph_download(g_default, particles, velocities);
 }
 
+// Page-locks a host range the caller owns so that uploads and downloads from it are direct DMA transfers instead of
+// copies through the runtime's staging buffers.  The pages stay locked until sph_host_unregister (or process exit).
+namespace {
+std::mutex g_pin_mu;
+std::vector<std::pair<void*, void*>> g_pinned;  // (caller's pointer, base the runtime was given)
+}  // namespace
+
+int sph_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return fail(SPH_ERR_INVALID, "bad host range");
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  for (auto& e : g_pinned)
+    if (e.first == p) return SPH_OK;
+  // whole pages: a malloc'd block rarely starts on a page boundary, and the first and last page may hold other
+  // heap data, which being page-locked does not harm
+  const uintptr_t page = 4096, a = (uintptr_t)p & ~(page - 1), b = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+  hipError_t e = hipHostRegister((void*)a, b - a, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) {
+    (void)hipGetLastError();
+    return SPH_OK;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SPH_ERR_HIP, "hipHostRegister(%zu bytes): %s", (size_t)(b - a), hipGetErrorString(e));
+  }
+  g_pinned.emplace_back(p, (void*)a);
+  return SPH_OK;
+}
+
+int sph_host_unregister(void* p) {
+  if (!p) return fail(SPH_ERR_INVALID, "NULL pointer");
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  for (size_t i = 0; i < g_pinned.size(); i++) {
+    if (g_pinned[i].first != p) continue;
+    const hipError_t e = hipHostUnregister(g_pinned[i].second);
+    g_pinned.erase(g_pinned.begin() + i);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(SPH_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
+    }
+    return SPH_OK;
+  }
+  return fail(SPH_ERR_INVALID, "this pointer was not registered through sph_host_register");
+}
+
 // ---- one-call step that allocates nothing -------------------------------------------------------------------
 // Same step as sph_update_particles, for callers that cannot allocate device memory (HIP graph capture, tight
 // serving loops, harnesses that forbid hipMalloc).  Every intermediate buffer of the step - SoA state, grid-sorted
