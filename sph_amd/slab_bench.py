@@ -154,7 +154,7 @@ def main(args):
     mine = np.nonzero((plane_col >= cuts[rank]) & (plane_col < cuts[rank + 1]))[0]
     i0, i1 = (int(mine[0]), int(mine[-1]) + 1) if mine.size else (0, 0)
     n_max = int(2.0 * n_total / world) + 4 * side_t * side_t * 8
-    rec_capacity = max(1 << 16, 48 * side_t * side_t)
+    rec_capacity = max(1 << 16, 64 * side_t * side_t)  # as the one-GPU runs of the same configurations
     sim = capi.SlabSimulation(p, n_max=n_max, col_lo=cuts[rank], col_hi=cuts[rank + 1], cols_capacity=gn,
                               device=dev_index, rec_capacity=1024 if library else rec_capacity)
     sim.fill_lattice(side_t, side_t, side_t, (i0, i1))  # every rank generates its own planes in HBM

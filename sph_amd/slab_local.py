@@ -105,8 +105,11 @@ def main():
     ap.add_argument("--slabs", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rebalance-every", type=int, default=2)
+    ap.add_argument("--n-max-factor", type=float, default=1.3,
+                    help="particle capacity of a slab in units of the mean slab (work-steered cut planes give a slab "
+                         "of uncompressed fluid more particles than one of compressed fluid)")
     a = ap.parse_args()
-    print(json.dumps(run(a.scene, a.side, a.slabs, a.steps, a.rebalance_every)))
+    print(json.dumps(run(a.scene, a.side, a.slabs, a.steps, a.rebalance_every, n_max_factor=a.n_max_factor)))
 
 
 if __name__ == "__main__":
