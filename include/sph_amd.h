@@ -183,6 +183,16 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
                          int num_particles);
 
 /*
+ * How sph_update_particles treats the caller's arrays.  Mode 0 (default): upload, step, download on every call - the
+ * caller may edit the arrays between calls, as the reference's interface allows.  Mode 1: a call with the same two
+ * pointers and particle count as the previous call skips the upload (the state in HBM is what those arrays hold,
+ * provided the caller has not written to them since - the reference's main loop, main.cpp:31-35, does not); both
+ * arrays are still written on return.  Any other pointers, count or a grid that outgrows the context upload as in
+ * mode 0.  Returns the previous mode; any other argument only queries.
+ */
+int sph_one_call_mode(int mode);
+
+/*
  * The one-call form moves 48 bytes per particle over PCIe every step (the reference's contract: host arrays valid on
  * return, render.cpp:240-253).  From ordinary (pageable) memory those transfers go through the runtime's staging
  * buffers; from page-locked memory they are direct DMA.  sph_host_register page-locks a range the caller allocated

@@ -19,9 +19,12 @@ else:
 pos = np.ascontiguousarray(pos, np.float32)
 vel = np.ascontiguousarray(vel, np.float32)
 pinned = len(sys.argv) > 3 and sys.argv[3] == "pinned"
+resident = len(sys.argv) > 3 and sys.argv[3] == "resident"
 if pinned:
     capi.host_register(pos)
     capi.host_register(vel)
+if resident:
+    capi.one_call_mode(1)
 for _ in range(5):
     capi.update_particles(pos, vel, params)
 t = []
@@ -30,5 +33,6 @@ for _ in range(calls):
     capi.update_particles(pos, vel, params)
     t.append(time.perf_counter() - t0)
 t = np.array(t) * 1e3
-print(json.dumps({"particles": n, "host_memory": "page-locked in place" if pinned else "pageable", "calls": calls, "ms_per_call_median": float(np.median(t)), "ms_per_call_mean": float(t.mean()),
+print(json.dumps({"particles": n, "host_memory": "page-locked in place" if pinned else "pageable",
+                  "one_call_mode": 1 if resident else 0, "calls": calls, "ms_per_call_median": float(np.median(t)), "ms_per_call_mean": float(t.mean()),
                   "particle_updates_per_s": n / (float(np.median(t)) * 1e-3), "bytes_over_pcie_per_call": 48 * n}))

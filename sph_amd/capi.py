@@ -48,6 +48,7 @@ _SIGNATURES = [
     ("sph_get_timings", C.c_int, [_CTX, C.POINTER(SphTimings)]),
     ("sph_reset_timings", C.c_int, [_CTX]),
     ("sph_update_particles", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int]),
+    ("sph_one_call_mode", C.c_int, [C.c_int]),
     ("sph_host_register", C.c_int, [C.c_void_p, C.c_size_t]),
     ("sph_host_unregister", C.c_int, [C.c_void_p]),
     ("sph_update_particles_noalloc", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -526,6 +527,12 @@ def update_particles(pos, vel, params=None):
     assert pos.dtype == np.float32 and vel.dtype == np.float32 and pos.flags.c_contiguous and vel.flags.c_contiguous
     _check(lib.sph_update_particles(C.byref(params) if params is not None else None, pos.ctypes.data,
                                     vel.ctypes.data, pos.size // 3))
+
+
+def one_call_mode(mode):
+    """0: every update_particles uploads; 1: a call with the same arrays as the last one skips the upload.  Returns
+    the previous mode."""
+    return int(load().sph_one_call_mode(int(mode)))
 
 
 def host_register(array):

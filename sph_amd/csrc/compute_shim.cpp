@@ -75,6 +75,12 @@ void initParticles(float** particles, float** velocities, int numParticles) {
 }
 
 void updateParticles(float* particles, float* velocities, int numParticles) {
+  static const bool once = [] {  // SPH_AMD_RESIDENT=1: the caller does not edit the arrays between steps (main.cpp:31-35)
+    const char* e = std::getenv("SPH_AMD_RESIDENT");
+    if (e && e[0] == '1') sph_one_call_mode(1);
+    return true;
+  }();
+  (void)once;
   sph_params p = params_from_globals();
   if (sph_update_particles(&p, particles, velocities, numParticles) != SPH_OK) die("updateParticles");
 }

@@ -1551,6 +1551,20 @@ int sph_set_stream(sph_context* c, void* stream) {
 // ---- one-call form of updateParticles on a process-wide default context ------------------------------------
 static std::mutex g_default_mu;
 static sph_context* g_default = nullptr;
+static int g_one_call_mode = 0;                 // sph_one_call_mode
+static const float* g_last_pos = nullptr;       // host arrays of the last successful call
+static const float* g_last_vel = nullptr;
+static int g_last_n = -1;
+
+int sph_one_call_mode(int mode) {
+  std::lock_guard<std::mutex> lock(g_default_mu);
+  const int before = g_one_call_mode;
+  if (mode == 0 || mode == 1) {
+    g_one_call_mode = mode;
+    g_last_n = -1;  // the next call uploads whatever the mode
+  }
+  return before;
+}
 
 int sph_update_particles(const sph_params* params, float* particles, float* velocities, int num_particles) {
   std::lock_guard<std::mutex> lock(g_default_mu);
@@ -1565,13 +1579,23 @@ int sph_update_particles(const sph_params* params, float* particles, float* velo
   if (need_new) {
     if (g_default) sph_destroy(g_default);
     g_default = nullptr;
+    g_last_n = -1;
     int dev = 0;
     if (const char* e = getenv("SPH_AMD_DEVICE")) dev = atoi(e);
     if ((rc = sph_create(&p, num_particles, dev, &g_default))) return rc;
   }
-  if ((rc = sph_upload(g_default, particles, velocities, num_particles))) return rc;
+  // mode 1: the caller promises not to touch the arrays between calls (the reference's main loop does not,
+  // main.cpp:31-35), so the state in HBM is what the host arrays hold and the upload can be skipped
+  const bool resident = g_one_call_mode == 1 && g_last_pos == particles && g_last_vel == velocities &&
+                        g_last_n == num_particles;
+  g_last_n = -1;
+  if (!resident && (rc = sph_upload(g_default, particles, velocities, num_particles))) return rc;
   if ((rc = sph_step(g_default, 1))) return rc;
-  return sph_download(g_default, particles, velocities);
+  if ((rc = sph_download(g_default, particles, velocities))) return rc;
+  g_last_pos = particles;
+  g_last_vel = velocities;
+  g_last_n = num_particles;
+  return SPH_OK;
 }
 
 // Page-locks a host range the caller owns so that uploads and downloads from it are direct DMA transfers instead of

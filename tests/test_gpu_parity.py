@@ -328,6 +328,34 @@ def test_one_call_update_particles(oracle):
     assert max_rel(pos, po) <= TOL_ONE_STEP * 3 and max_rel(vel, vo) <= 1e-4
 
 
+def test_one_call_mode_that_skips_the_upload():
+    """sph_one_call_mode(1): calls with the same arrays skip the upload and give the bits of the default mode; a
+    caller that does edit its arrays is served from HBM until it hands over other arrays or switches the mode back -
+    the documented price of the mode."""
+    pos, vel = scenes.random_block(4000, seed=8)
+    p = default_params()
+    a_pos, a_vel, b_pos, b_vel = pos.copy(), vel.copy(), pos.copy(), vel.copy()
+    for _ in range(4):
+        capi.update_particles(a_pos, a_vel, p)
+    assert capi.one_call_mode(1) == 0
+    try:
+        for _ in range(4):
+            capi.update_particles(b_pos, b_vel, p)
+        assert bits_equal(a_pos, b_pos) and bits_equal(a_vel, b_vel)
+        # an edit between calls is NOT seen in this mode ...
+        c_pos, c_vel = b_pos.copy(), b_vel.copy()      # the state after four steps, as it stands in HBM
+        b_pos[0] += np.float32(0.01)
+        capi.update_particles(a_pos, a_vel, p)          # default-mode reference of step 5 (other arrays: uploads)
+        capi.update_particles(c_pos, c_vel, p)          # other arrays again: uploads the unedited state
+        assert bits_equal(c_pos, a_pos) and bits_equal(c_vel, a_vel)
+        # ... and is seen again once the mode is switched back
+        assert capi.one_call_mode(0) == 1
+        capi.update_particles(b_pos, b_vel, p)
+        assert not bits_equal(b_pos, a_pos)
+    finally:
+        capi.one_call_mode(0)
+
+
 def test_device_resident_io():
     torch = pytest.importorskip("torch")
     pos, vel = scenes.random_block(5000, seed=2)
