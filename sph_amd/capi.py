@@ -320,6 +320,7 @@ class SlabSimulation:
         _check(self.lib.sph_slab_create(C.byref(self.params), int(n_max), int(device), int(col_lo), int(col_hi),
                                         int(cols_capacity), C.byref(self._ctx)))
         self.n_max = int(n_max)
+        self.cols_capacity = max(int(cols_capacity), int(col_hi) - int(col_lo))  # the widest this slab may become
         self.device = torch.device("cuda", device)
         self.rec_capacity = int(rec_capacity if rec_capacity is not None else max(1024, n_max // 4))
         self._send_left = torch.empty((self.rec_capacity, RECORD_WORDS), dtype=torch.float32, device=self.device)

@@ -66,8 +66,9 @@ def face_move_for_shift(max_shift_columns):
     return int(min(MAX_FACE_MOVE, max(1, np.ceil(max_shift_columns))))
 
 
-def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
-    """Move every interior cut by at most max_shift columns towards the balanced partition."""
+def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS, max_cols=None):
+    """Move every interior cut by at most max_shift columns towards the balanced partition.  max_cols: the widest each
+    slab may become (a context's column capacity), one number or one per slab."""
     nranks = len(cuts) - 1
     ncols = cuts[-1]
     min_cols = min(min_cols, ncols // nranks)  # never ask for more than the tank can give
@@ -85,6 +86,19 @@ def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS):
     # column, not more (a slab that is still too narrow keeps widening on the following calls)
     for r in range(1, nranks):
         new[r] = int(np.clip(new[r], cuts[r] - max_shift, cuts[r] + max_shift))
+    if max_cols is not None:
+        cap = [int(max_cols)] * nranks if np.isscalar(max_cols) else [int(c) for c in max_cols]
+        fit = list(new)
+        for r in range(nranks - 1):          # a slab that would outgrow its capacity hands columns to its right neighbour
+            fit[r + 1] = min(fit[r + 1], fit[r] + cap[r])
+        for r in range(nranks - 1, 0, -1):   # ... and the last ones to their left neighbours
+            fit[r] = max(fit[r], fit[r + 1] - cap[r])
+        ok = all(fit[r + 1] - fit[r] <= cap[r] and fit[r + 1] - fit[r] >= min_cols for r in range(nranks)) and \
+            all(abs(fit[r] - cuts[r]) <= max_shift for r in range(1, nranks))
+        if ok:
+            new = fit
+        elif any(new[r + 1] - new[r] > cap[r] for r in range(nranks)):
+            new = list(cuts)                 # no admissible move this time: the planes stay where they are
     return new
 
 
@@ -364,7 +378,8 @@ def rebalance_next_local_slabs(backends, cuts, by="work", stats=None, max_move=N
         stats["load"] = [int(hist[cuts[r]:cuts[r + 1]].sum()) for r in range(len(backends))]
         stats["shift"] = shift
     move = face_move_for_shift(shift) if max_move is None else max_move
-    new = rebalance_cuts(cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move))
+    caps = [getattr(b, "cols_capacity", cuts[-1]) or cuts[-1] for b in backends]
+    new = rebalance_cuts(cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move), max_cols=caps)
     for r, b in enumerate(backends):
         b.set_face_shift(shift)
         b.set_next_columns(new[r], new[r + 1])

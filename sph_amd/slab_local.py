@@ -41,7 +41,7 @@ def build(scene, side, nslabs, rec_factor=64, n_max_factor=1.3):
         i0, i1 = (int(mine[0]), int(mine[-1]) + 1) if mine.size else (0, 0)
         # room for the cut planes to wander (8 B per cell: a full-width grid for every slab would be tens of GB)
         b = capi.SlabSimulation(p, n_max=n_max, col_lo=cuts[r], col_hi=cuts[r + 1],
-                                cols_capacity=min(gn, cuts[r + 1] - cuts[r] + 64),
+                                cols_capacity=min(gn, cuts[r + 1] - cuts[r] + max(64, gn // 3)),
                                 rec_capacity=1024)  # the pack/append buffers of the caller-driven protocol are not used
         b.fill_lattice(side, side, side, (i0, i1))
         backends.append(b)

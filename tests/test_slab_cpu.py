@@ -191,3 +191,17 @@ def test_library_runner_rebalances_consistently_over_gloo():
     for r, pr in enumerate(procs):
         assert pr.returncode == 0, f"rank {r} failed:\n{outs[r]}"
     assert "CONSISTENT" in outs[0], outs[0]
+
+
+def test_rebalance_respects_column_capacities():
+    """A slab whose context can hold only so many columns is never asked to grow beyond that: the surplus goes to its
+    neighbours, and when no admissible move exists the planes stay."""
+    hist = np.zeros(60, np.int64)
+    hist[50:] = 100  # everything on the right: slab 0 would like to swallow the empty left half
+    cuts = [0, 12, 24, 60]
+    for _ in range(40):
+        cuts = slab.rebalance_cuts(cuts, hist, max_shift=3, min_cols=4, max_cols=[20, 30, 40])
+        assert cuts[1] - cuts[0] <= 20 and cuts[2] - cuts[1] <= 30 and cuts[3] - cuts[2] <= 40
+    assert cuts[1] == 20 and cuts[2] == 50          # as far right as the capacities allow
+    free = slab.rebalance_cuts([0, 12, 24, 60], hist, max_shift=3, min_cols=4)
+    assert free[1] == 15 and free[2] == 27         # without capacities: three columns per call towards the load
