@@ -60,10 +60,19 @@ def min_columns_for_shift(max_shift_columns, face_move=1):
     return max(MIN_SLAB_COLUMNS, int(np.ceil(max_shift_columns)) + 2 + int(face_move))
 
 
-def face_move_for_shift(max_shift_columns):
+def face_move_for_shift(max_shift_columns, cuts=None):
     """Columns a cut plane may travel per step: as many as the fastest particle crosses, so that the planes can follow a
-    front (a dam-break front runs at 2-4 columns per step), within what one exchange covers."""
-    return int(min(MAX_FACE_MOVE, max(1, np.ceil(max_shift_columns))))
+    front (a dam-break front runs at 2-4 columns per step), within what one exchange covers.  Every column of travel
+    is a column of minimum slab width (min_columns_for_shift), so where fluid piles up against a wall and the slabs
+    there want to become narrow, the planes slow down rather than keep the slabs wide: given the cuts, the move is
+    limited to what the narrowest slab can afford."""
+    move = int(min(MAX_FACE_MOVE, max(1, np.ceil(max_shift_columns))))
+    if cuts is not None:
+        narrowest = min(b - a for a, b in zip(cuts, cuts[1:]))
+        # one column less than the narrowest slab could afford: a slab under pressure can then still narrow by a column
+        # per call, down to the width that planes moving one column per step allow
+        move = max(1, min(move, narrowest - int(np.ceil(max_shift_columns)) - 3))
+    return move
 
 
 def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS, max_cols=None):
@@ -98,7 +107,13 @@ def rebalance_cuts(cuts, hist, max_shift=1, min_cols=MIN_SLAB_COLUMNS, max_cols=
         if ok:
             new = fit
         elif any(new[r + 1] - new[r] > cap[r] for r in range(nranks)):
-            new = list(cuts)                 # no admissible move this time: the planes stay where they are
+            # plane by plane from where they stand: a plane takes its move if both slabs beside it stay admissible
+            work = list(cuts)
+            for r in range(1, nranks):
+                left, right = new[r] - work[r - 1], work[r + 1] - new[r]
+                if min_cols <= left <= cap[r - 1] and min_cols <= right <= cap[r]:
+                    work[r] = new[r]
+            new = work
     return new
 
 
@@ -377,7 +392,7 @@ def rebalance_next_local_slabs(backends, cuts, by="work", stats=None, max_move=N
     if stats is not None:
         stats["load"] = [int(hist[cuts[r]:cuts[r + 1]].sum()) for r in range(len(backends))]
         stats["shift"] = shift
-    move = face_move_for_shift(shift) if max_move is None else max_move
+    move = face_move_for_shift(shift, cuts) if max_move is None else max_move
     caps = [getattr(b, "cols_capacity", cuts[-1]) or cuts[-1] for b in backends]
     new = rebalance_cuts(cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move), max_cols=caps)
     for r, b in enumerate(backends):
@@ -451,7 +466,7 @@ class LibraryRunner:
         # one column of margin: the shift was measured up to rebalance_every + 1 steps before the faces it sizes are used
         raw = float(full[ncols:].max()) / 1024.0
         hist, shift = full[:ncols], raw + 1.0
-        move = face_move_for_shift(raw)
+        move = face_move_for_shift(raw, self.cuts)
         new = rebalance_cuts(self.cuts, hist, max_shift=move, min_cols=min_columns_for_shift(shift, move))
         b.set_face_shift(shift)
         b.set_next_columns(new[self.rank], new[self.rank + 1])
