@@ -307,7 +307,8 @@ def main():
                    "h": float(r["params"].h), "surface_tension": True, "parallelism": "1 GPU",
                    "arithmetic": "fast (fp32 coefficients, refined rcp/rsq); neighbour sets exact"},
         "phase": {"preroll_steps": args.preroll, "timed_steps": [first, first + steps],
-                  "description": ("peak compression of the dam-break collapse (~50 neighbours per particle)"
+                  "description": ("the window starts at the peak compression of the dam-break collapse (~50 neighbours per "
+                                  "particle; its first 20 steps are the most expensive 20 of the run)"
                                   if args.workload == "dam_break" and args.preroll == peak_preroll(args.side) else
                                   f"{args.preroll} steps after the initial state")},
     }
