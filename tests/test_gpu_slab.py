@@ -467,8 +467,8 @@ def test_rccl_send_recv_on_one_gpu():
     assert float(recv_right[0]) == -1.0 and float(recv_right[7 * 100]) == -1.0
 
 
-@pytest.mark.parametrize("by", ["count", "work"])
-def test_cut_planes_travelling_every_step_lose_nothing(oracle, by):
+@pytest.mark.parametrize("by,max_move", [("count", None), ("work", None), ("work", 6)])
+def test_cut_planes_travelling_every_step_lose_nothing(oracle, by, max_move):
     """Three slabs cut badly on purpose (nearly everything in the middle one), rebalanced after EVERY step, so that
     every face moves a column per step for many steps: the records of a step are packed for the faces of the next one
     and must be judged against that grid when they arrive (nothing counted as stray, nothing missed), and the result
@@ -489,13 +489,16 @@ def test_cut_planes_travelling_every_step_lose_nothing(oracle, by):
         backends.append(b)
     attach_chain(backends, rec_capacity=1 << 17)
     slab.halo_local_slabs(backends)
-    moved = 0
+    moved = jumps = 0
     for s in range(30):
         slab.step_local_slabs_overlapped(backends)
-        new = slab.rebalance_next_local_slabs(backends, cuts, by=by)
+        new = slab.rebalance_next_local_slabs(backends, cuts, by=by, max_move=max_move)
         moved += sum(abs(a - c) for a, c in zip(new, cuts))
+        if max_move:
+            jumps = max(jumps, max(abs(a - c) for a, c in zip(new, cuts)))
         cuts = new
     assert moved >= 12, f"the cut planes hardly moved: {cuts}"
+    assert not max_move or jumps >= 4, "planes allowed six columns per step must have jumped several at once"
     with capi.Simulation(p, n_max=ids.size) as single:
         single.upload(pos, vel)
         single.step(30)
