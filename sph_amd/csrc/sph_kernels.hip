@@ -203,7 +203,13 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ cou
   int v[kPerThread];
   int s = 0;
   bool full = base + kPerThread <= ncells;
-  if (full) {
+  // A tile without particles (most of a tank whose fluid fills a corner): its raw sum says so, and then its cells
+  // need neither be read nor re-zeroed - only their start entries written, all equal.
+  const bool empty_tile = sums_are_raw && block_sums[blockIdx.x] == 0;
+  if (empty_tile) {
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) v[k] = 0;
+  } else if (full) {
     int4* p = reinterpret_cast<int4*>(count + base);
 #pragma unroll
     for (int k = 0; k < kPerThread / 4; k++) {
