@@ -205,3 +205,18 @@ def test_rebalance_respects_column_capacities():
     assert cuts[1] == 20 and cuts[2] == 50          # as far right as the capacities allow
     free = slab.rebalance_cuts([0, 12, 24, 60], hist, max_shift=3, min_cols=4)
     assert free[1] == 15 and free[2] == 27         # without capacities: three columns per call towards the load
+
+
+def test_face_moves_follow_the_front_and_yield_to_narrow_slabs():
+    """Planes travel as many columns per step as the fastest particle crosses (within the exchange's limit), every
+    column of travel widens the minimum slab, and where the narrowest slab cannot afford that the planes slow down so
+    that slabs under pressure can narrow by a column per call."""
+    assert slab.face_move_for_shift(0.3) == 1 and slab.face_move_for_shift(2.2) == 3
+    assert slab.face_move_for_shift(50.0) == slab.MAX_FACE_MOVE
+    assert slab.min_columns_for_shift(2.2, face_move=3) == 3 + 2 + 3
+    assert slab.min_columns_for_shift(0.0) == slab.MIN_SLAB_COLUMNS
+    wide = [0, 40, 80, 120]
+    assert slab.face_move_for_shift(3.5, wide) == 4
+    tight = [0, 40, 50, 120]                       # a 10-column slab at a shift of 3.5 columns per step
+    assert slab.face_move_for_shift(3.5, tight) == 3   # 4 + 2 + 3 = 9 < 10: the slab may still narrow
+    assert slab.face_move_for_shift(3.5, [0, 40, 47, 120]) == 1
