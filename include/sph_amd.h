@@ -286,6 +286,28 @@ int sph_render_frame(sph_context* ctx, const sph_camera* cam, int width, int hei
 
 /* Cells per axis of the global grid for these parameters. */
 int sph_global_cells(const sph_params* params, int* cells_per_axis);
+/* Global cell column of the coordinate x: the device's own expression (fp32 x / cell edge, floor, clamped to the grid),
+ * so that a host that deals particles out to slabs puts every one where the sort will find it.  Host arithmetic. */
+int sph_column_of(const sph_params* params, float x, int* column);
+
+/* Cut planes.  Host arithmetic only (no device is touched): one implementation for drivers in any language.
+ * load[c] is what global column c costs - particles, or the work figure of sph_slab_load_work; cuts[0..nslabs] with
+ * cuts[0] = 0 and cuts[nslabs] = ncols, slab r owning columns [cuts[r], cuts[r+1]).
+ *   sph_slab_plan_partition   the cuts whose cumulative load is closest to equal shares, every slab >= min_cols wide.
+ *   sph_slab_plan_next        the cuts for the records of the next step: every interior plane moves towards the
+ *                             balanced partition by at most *face_move columns - as many as the fastest particle
+ *                             crosses per step (column_shift, the largest sph_slab_max_column_shift of all slabs), at
+ *                             most SPH_SLAB_MAX_FACE_MOVE, fewer when the narrowest slab cannot afford them - keeping
+ *                             every slab at least ceil(column_shift + shift_margin) + 2 + *face_move columns wide and,
+ *                             with cols_capacity (one entry per slab, or NULL), no wider than its context allows.
+ *                             shift_margin: columns of allowance for a shift measured some steps before the planes it
+ *                             sizes are used (0 when measured between the same two steps).  *face_shift = column_shift
+ *                             + shift_margin is what sph_slab_set_face_shift wants; next_cuts[r], next_cuts[r+1] what
+ *                             sph_slab_set_next_columns of slab r wants.  face_move and face_shift may be NULL. */
+int sph_slab_plan_partition(const int64_t* load, int ncols, int nslabs, int min_cols, int32_t* cuts);
+int sph_slab_plan_next(const int64_t* load, int ncols, int nslabs, const int32_t* cuts, float column_shift,
+                       float shift_margin, const int32_t* cols_capacity, int32_t* next_cuts, int* face_move,
+                       float* face_shift);
 
 /* Like sph_create, for the slab [col_lo, col_hi); cols_capacity (>= col_hi - col_lo) bounds how
  * wide the slab may become through sph_slab_set_columns. */

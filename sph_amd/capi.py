@@ -57,6 +57,10 @@ _SIGNATURES = [
     ("sph_fill_random_block", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     # slab decomposition
     ("sph_global_cells", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("sph_column_of", C.c_int, [_P, C.c_float, C.POINTER(C.c_int)]),
+    ("sph_slab_plan_partition", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("sph_slab_plan_next", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ("sph_slab_create", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_CTX)]),
     ("sph_slab_set_columns", C.c_int, [_CTX, C.c_int, C.c_int]),
     ("sph_slab_get_columns", C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -302,6 +306,37 @@ def global_cells(params):
     n = C.c_int()
     _check(load().sph_global_cells(C.byref(params), C.byref(n)))
     return n.value
+
+
+def column_of(params, x):
+    """Global cell column of coordinate x, by the library's own expression (host arithmetic)."""
+    c = C.c_int()
+    _check(load().sph_column_of(C.byref(params), float(x), C.byref(c)))
+    return c.value
+
+
+def plan_partition(load_per_column, nslabs, min_cols=MIN_SLAB_COLUMNS):
+    """sph_slab_plan_partition: balanced cuts[0..nslabs] over the columns (host arithmetic, no device)."""
+    hist = np.ascontiguousarray(load_per_column, dtype=np.int64)
+    cuts = np.zeros(nslabs + 1, np.int32)
+    _check(load().sph_slab_plan_partition(hist.ctypes.data, hist.size, nslabs, min_cols, cuts.ctypes.data))
+    return [int(c) for c in cuts]
+
+
+def plan_next(load_per_column, cuts, column_shift, shift_margin=0.0, cols_capacity=None):
+    """sph_slab_plan_next: (next cuts, face move, face shift) for the records of the next step."""
+    hist = np.ascontiguousarray(load_per_column, dtype=np.int64)
+    now = np.ascontiguousarray(cuts, dtype=np.int32)
+    nslabs = now.size - 1
+    caps = None if cols_capacity is None else np.ascontiguousarray(cols_capacity, dtype=np.int32)
+    if caps is not None and caps.size != nslabs:
+        raise ValueError("cols_capacity needs one entry per slab")
+    out = np.zeros(nslabs + 1, np.int32)
+    move, shift = C.c_int(), C.c_float()
+    _check(load().sph_slab_plan_next(hist.ctypes.data, hist.size, nslabs, now.ctypes.data, float(column_shift),
+                                     float(shift_margin), None if caps is None else caps.ctypes.data, out.ctypes.data,
+                                     C.byref(move), C.byref(shift)))
+    return [int(c) for c in out], move.value, shift.value
 
 
 class SlabSimulation:

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -780,6 +781,123 @@ int sph_global_cells(const sph_params* p, int* cells) {
   int gn = cells_per_axis(p);
   if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
   *cells = gn;
+  return SPH_OK;
+}
+
+int sph_column_of(const sph_params* p, float x, int* column) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!column) return fail(SPH_ERR_INVALID, "NULL argument");
+  int gn = cells_per_axis(p);
+  if (gn < 0) return fail(SPH_ERR_CAPACITY, "tank_size/cell_size needs more than 2048 cells per axis");
+  // the expression of the device's cell_coord (fp32 division, then clamp; a NaN lands in column 0)
+  float q = floorf(x / resolved_cell(p));
+  q = fminf(fmaxf(q, 0.0f), (float)(gn - 1));
+  *column = (int)q;
+  return SPH_OK;
+}
+
+// ---- cut planes (host arithmetic only) ---------------------------------------------------------------------------
+
+namespace {
+
+int ceil_columns(float v) { return (int)ceilf(v > 0.0f ? v : 0.0f); }
+
+// cuts[0..nslabs]: boundaries whose cumulative load is closest to r/nslabs of the total, every slab >= min_cols wide.
+void balanced_cuts(const int64_t* load, int ncols, int nslabs, int min_cols, std::vector<int>* out) {
+  std::vector<int64_t> csum((size_t)ncols + 1, 0);
+  for (int i = 0; i < ncols; i++) csum[i + 1] = csum[i] + load[i];
+  const int64_t total = csum[ncols];
+  std::vector<int>& cuts = *out;
+  cuts.assign(1, 0);
+  for (int r = 1; r < nslabs; r++) {
+    const double target = (double)(total * r) / (double)nslabs;
+    int c = 0;
+    while (c < ncols && (double)csum[c] < target) c++;  // first boundary at or beyond the target
+    if (c > 0 && fabs((double)csum[c - 1] - target) <= fabs((double)csum[c] - target)) c--;
+    const int lo = cuts.back() + min_cols, hi = ncols - (nslabs - r) * min_cols;
+    cuts.push_back(c < lo ? lo : (c > hi ? hi : c));
+  }
+  cuts.push_back(ncols);
+}
+
+int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace
+
+int sph_slab_plan_partition(const int64_t* load, int ncols, int nslabs, int min_cols, int32_t* cuts) {
+  if (!load || !cuts) return fail(SPH_ERR_INVALID, "NULL argument");
+  if (ncols < 1 || nslabs < 1 || min_cols < 1) return fail(SPH_ERR_INVALID, "ncols, nslabs and min_cols must be >= 1");
+  if ((int64_t)nslabs * min_cols > ncols)
+    return fail(SPH_ERR_INVALID, "%d columns cannot hold %d slabs of >= %d columns", ncols, nslabs, min_cols);
+  for (int i = 0; i < ncols; i++)
+    if (load[i] < 0) return fail(SPH_ERR_INVALID, "load[%d] is negative", i);
+  std::vector<int> v;
+  balanced_cuts(load, ncols, nslabs, min_cols, &v);
+  for (int r = 0; r <= nslabs; r++) cuts[r] = v[r];
+  return SPH_OK;
+}
+
+int sph_slab_plan_next(const int64_t* load, int ncols, int nslabs, const int32_t* cuts, float column_shift,
+                       float shift_margin, const int32_t* cols_capacity, int32_t* next_cuts, int* face_move,
+                       float* face_shift) {
+  if (!load || !cuts || !next_cuts) return fail(SPH_ERR_INVALID, "NULL argument");
+  if (ncols < 1 || nslabs < 1) return fail(SPH_ERR_INVALID, "ncols and nslabs must be >= 1");
+  if (!(column_shift >= 0.0f) || !(shift_margin >= 0.0f)) return fail(SPH_ERR_INVALID, "shifts must be >= 0");
+  if (cuts[0] != 0 || cuts[nslabs] != ncols) return fail(SPH_ERR_INVALID, "cuts must run from 0 to ncols");
+  int narrowest = ncols;
+  for (int r = 0; r < nslabs; r++) {
+    if (cuts[r + 1] <= cuts[r]) return fail(SPH_ERR_INVALID, "cuts must increase");
+    narrowest = std::min(narrowest, cuts[r + 1] - cuts[r]);
+  }
+  for (int i = 0; i < ncols; i++)
+    if (load[i] < 0) return fail(SPH_ERR_INVALID, "load[%d] is negative", i);
+
+  // Columns a plane may travel: as many as the fastest particle crosses, so that planes can follow a front, within
+  // what one exchange covers; one column less than the narrowest slab could afford, so that a slab under pressure
+  // (fluid piling up at a wall) can still narrow by a column per call.
+  int move = std::min(SPH_SLAB_MAX_FACE_MOVE, std::max(1, ceil_columns(column_shift)));
+  move = std::max(1, std::min(move, narrowest - ceil_columns(column_shift) - 3));
+  const float shift = column_shift + shift_margin;
+  // narrowest slab one exchange per step can serve: ceil(shift) + 2 ghost columns + the planes' own travel
+  int min_cols = std::max(SPH_SLAB_MIN_COLUMNS, ceil_columns(shift) + 2 + move);
+  min_cols = std::min(min_cols, ncols / nslabs);  // never more than the tank can give
+  if (min_cols < 1) return fail(SPH_ERR_INVALID, "%d columns cannot hold %d slabs", ncols, nslabs);
+
+  std::vector<int> ideal, now(cuts, cuts + nslabs + 1), next;
+  balanced_cuts(load, ncols, nslabs, min_cols, &ideal);
+  next = now;
+  for (int r = 1; r < nslabs; r++) next[r] = now[r] + clampi(ideal[r] - now[r], -move, move);
+  for (int r = 1; r < nslabs; r++) next[r] = std::max(next[r], next[r - 1] + min_cols);  // minimum widths ...
+  for (int r = nslabs - 1; r > 0; r--) next[r] = std::min(next[r], next[r + 1] - min_cols);
+  for (int r = 1; r < nslabs; r++) next[r] = clampi(next[r], now[r] - move, now[r] + move);  // ... never beyond `move`
+  if (cols_capacity) {
+    const int32_t* cap = cols_capacity;
+    std::vector<int> fit = next;
+    for (int r = 0; r + 1 < nslabs; r++) fit[r + 1] = std::min(fit[r + 1], fit[r] + cap[r]);  // too wide: columns go right
+    for (int r = nslabs - 1; r > 0; r--) fit[r] = std::max(fit[r], fit[r + 1] - cap[r]);      // ... and the last ones left
+    bool ok = true, too_wide = false;
+    for (int r = 0; r < nslabs; r++) {
+      const int w = fit[r + 1] - fit[r];
+      ok = ok && w <= cap[r] && w >= min_cols;
+      too_wide = too_wide || next[r + 1] - next[r] > cap[r];
+    }
+    for (int r = 1; r < nslabs; r++) ok = ok && abs(fit[r] - now[r]) <= move;
+    if (ok) {
+      next = fit;
+    } else if (too_wide) {
+      // plane by plane from where they stand: a plane takes its move if both slabs beside it stay admissible
+      std::vector<int> work = now;
+      for (int r = 1; r < nslabs; r++) {
+        const int left = next[r] - work[r - 1], right = work[r + 1] - next[r];
+        if (left >= min_cols && left <= cap[r - 1] && right >= min_cols && right <= cap[r]) work[r] = next[r];
+      }
+      next = work;
+    }
+  }
+  for (int r = 0; r <= nslabs; r++) next_cuts[r] = next[r];
+  if (face_move) *face_move = move;
+  if (face_shift) *face_shift = shift;
   return SPH_OK;
 }
 

@@ -190,3 +190,48 @@ def test_headless_writes_pictures(tmp_path):
     r = subprocess.run([HEADLESS, "--n", "100", "--steps", "1", "--mode", "shim", "--frames-every", "1"], capture_output=True,
                        text=True, cwd=tmp_path, timeout=300)
     assert r.returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,side,slabs", [("dam", 40, 4), ("slosh", 36, 3)])
+def test_headless_slabs_match_the_single_context(tmp_path, scene, side, slabs):
+    """--slabs K: K slab contexts driven from C++ alone (sph_column_of, sph_slab_plan_partition, sph_slab_upload,
+    sph_slab_attach_local, sph_slab_step_begin/_end, sph_slab_load_work -> sph_slab_plan_next -> sph_slab_set_next_columns)
+    give the single context's dumps bit for bit, mid-run and at the end, with the cut planes moving; and a run resumed
+    from a dump of the slab run continues to the same bits."""
+    import json
+
+    def run(*args):
+        r = subprocess.run([HEADLESS, *args], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    common = ["--scene", scene, "--side", str(side), "--steps", "40", "--mode", "resident", "--dump-every", "20"]
+    one = run(*common, "--out", "one")
+    many = run(*common, "--slabs", str(slabs), "--rebalance-every", "2", "--out", "many")
+    assert many["slabs"] == slabs and many["lost"] == 0 and many["missed"] == 0 and many["rebalances"] == 20
+    assert sum(many["own"]) == side ** 3 == one["n"]
+    for name in ("000020", "final"):
+        _, s1, p1, v1 = dumpio.read_dump(tmp_path / f"one_{name}.sphd")
+        _, s2, p2, v2 = dumpio.read_dump(tmp_path / f"many_{name}.sphd")
+        assert s1 == s2 and bits_equal(p1, p2) and bits_equal(v1, v2), name
+    cont = run("--resume", "many_000020.sphd", "--scene", scene, "--steps", "20", "--mode", "resident", "--slabs", str(slabs),
+               "--out", "cont")
+    _, s3, p3, v3 = dumpio.read_dump(tmp_path / "cont_final.sphd")
+    assert s3 == 40 and bits_equal(p3, p2) and bits_equal(v3, v2) and cont["lost"] == 0
+    # the collapsing dam drags the cut planes away from where the resting block put them (40 steps of a 15-degree swing
+    # do not)
+    start = run("--scene", scene, "--side", str(side), "--steps", "1", "--mode", "resident", "--slabs", str(slabs),
+                "--rebalance-every", "0", "--out", "start")
+    assert start["rebalances"] == 0 and (start["cuts"] != many["cuts"] or scene != "dam")
+
+
+@pytest.mark.gpu
+def test_headless_slabs_refuse_what_they_cannot_do(tmp_path):
+    r = subprocess.run([HEADLESS, "--n", "500", "--steps", "1", "--mode", "shim", "--slabs", "2"], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=300)
+    assert r.returncode == 2
+    # more slabs than the grid has room for (four columns each)
+    r = subprocess.run([HEADLESS, "--n", "500", "--steps", "1", "--mode", "resident", "--slabs", "500"], capture_output=True,
+                       text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 1 and "cannot hold" in r.stderr

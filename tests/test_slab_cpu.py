@@ -220,3 +220,77 @@ def test_face_moves_follow_the_front_and_yield_to_narrow_slabs():
     tight = [0, 40, 50, 120]                       # a 10-column slab at a shift of 3.5 columns per step
     assert slab.face_move_for_shift(3.5, tight) == 3   # 4 + 2 + 3 = 9 < 10: the slab may still narrow
     assert slab.face_move_for_shift(3.5, [0, 40, 47, 120]) == 1
+
+
+def test_library_cut_planner_agrees_with_the_python_one():
+    """sph_slab_plan_partition / sph_slab_plan_next (what a native driver calls) against partition_columns /
+    face_move_for_shift / min_columns_for_shift / rebalance_cuts on random column loads, shifts and capacities."""
+    from sph_amd import capi
+    rng = np.random.default_rng(7)
+    cases = 0
+    for trial in range(400):
+        ncols = int(rng.integers(8, 200))
+        nslabs = int(rng.integers(1, max(2, ncols // 8) + 1))
+        kind = trial % 4
+        if kind == 0:
+            hist = rng.integers(0, 1000, ncols)
+        elif kind == 1:   # a block in one corner: most columns empty
+            hist = np.zeros(ncols, np.int64)
+            hist[: ncols // 3] = rng.integers(1, 500, ncols // 3)
+        elif kind == 2:   # fluid piled up against the far wall
+            hist = (np.arange(ncols) ** 3).astype(np.int64)
+        else:
+            hist = np.zeros(ncols, np.int64)
+        min_cols = int(rng.integers(1, max(2, ncols // nslabs) + 1))
+        if nslabs * min_cols > ncols:
+            with pytest.raises(capi.SphError):
+                capi.plan_partition(hist, nslabs, min_cols)
+            continue
+        cuts = slab.partition_columns(hist, nslabs, min_cols)
+        assert capi.plan_partition(hist, nslabs, min_cols) == cuts
+        # planes somewhere else than the balanced partition, a front of some speed, contexts of some capacity
+        other = slab.partition_columns(rng.integers(0, 1000, ncols), nslabs, min_cols)
+        shift = float(np.float32(rng.choice([0.0, 0.3, 1.0, 1.7, 2.5, 4.2, 9.5])))
+        margin = float(rng.choice([0.0, 1.0]))
+        widths = np.diff(other)
+        caps = None if trial % 3 == 0 else [int(w + rng.integers(0, 12)) for w in widths]
+        move = slab.face_move_for_shift(shift, other)
+        want = slab.rebalance_cuts(other, hist, max_shift=move,
+                                   min_cols=slab.min_columns_for_shift(shift + margin, move), max_cols=caps)
+        got, got_move, got_shift = capi.plan_next(hist, other, shift, margin, caps)
+        assert got_move == move and got == want, (trial, ncols, nslabs, other, shift, margin, caps)
+        assert got_shift == pytest.approx(shift + margin)
+        assert got[0] == 0 and got[-1] == ncols and all(abs(a - b) <= move for a, b in zip(got, other))
+        cases += 1
+    assert cases > 200
+
+
+def test_library_cut_planner_refuses_bad_cuts():
+    from sph_amd import capi
+    hist = np.ones(32, np.int64)
+    for bad in ([1, 16, 32], [0, 16, 31], [0, 20, 20, 32], [0, 20, 10, 32]):
+        with pytest.raises(capi.SphError):
+            capi.plan_next(hist, bad, 1.0)
+    with pytest.raises(capi.SphError):
+        capi.plan_next(-hist, [0, 16, 32], 1.0)
+    with pytest.raises(capi.SphError):
+        capi.plan_next(hist, [0, 16, 32], -1.0)
+
+
+def test_column_of_is_the_sort_s_column():
+    """sph_column_of against the oracle's cell index (reference compute.cpp has no grid: the oracle's cell ids are the
+    ones the GPU sort is tested against) on random coordinates and on the cell faces themselves."""
+    from oracle import Oracle
+    from sph_amd import capi
+    p = default_params()
+    gn = capi.global_cells(p)
+    cell = np.float32(p.h) * np.float32(1.000244140625)
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-0.05, p.tank_size + 0.05, 500).astype(np.float32),
+                         (np.arange(0, gn + 1, dtype=np.float32) * cell),
+                         np.nextafter(np.arange(1, gn + 1, dtype=np.float32) * cell, np.float32(0))])
+    pos = np.zeros((xs.size, 3), np.float32)
+    pos[:, 0] = xs
+    want = Oracle().cell_ids(p, pos) // (gn * gn)
+    got = np.array([capi.column_of(p, x) for x in xs])
+    assert np.array_equal(got, want)
