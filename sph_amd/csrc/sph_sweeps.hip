@@ -11,7 +11,9 @@
 // Default (SWEEP_MASKED) pipeline, one lane per particle in every kernel:
 //   k_neighbours  the only kernel that tests distances: walks the flattened stencil four candidates per trip
 //                 (48 packed bytes, three 16-byte gathers) and records WHICH candidates satisfy sqrtf(r2) <= h as a
-//                 bitmask per particle, plus the candidate and neighbour counts;
+//                 bitmask per particle, plus the candidate and neighbour counts.  Every run of the stencil is padded to
+//                 whole trips in the mask (a run of len candidates owns 4 * ceil(len / 4) bit positions), so trip t of a
+//                 particle fills bits 4t .. 4t+3 whatever came before;
 //   k_density     walks the set bits: every loop trip is a true neighbour, so the sqrt / double-precision
 //                 kernel arithmetic runs with the wave's lanes busy instead of ~20 % of them;
 //   k_force       same walk with the pair arithmetic of :153-262, then Euler step and wall reflection.
@@ -22,6 +24,8 @@
 //   SWEEP_PLAIN  tests and evaluates in one loop (no mask); same results bit for bit as SWEEP_MASKED;
 //   SWEEP_EXACT  sums neighbours in ascending particle id, the order in which the reference's j = 0..N-1
 //                loops meet the non-zero terms: bit-identical to the reference.
+#include <type_traits>
+
 #include "sph_device.hpp"
 
 namespace sph {
@@ -111,8 +115,8 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
 // The 9 stencil runs of every lane's particle, fetched up front (18 independent loads, one latency) into a
 // per-lane column of LDS, so that stepping from run to run inside the sweeps is an LDS read instead of two
 // dependent global loads that would stall the whole wave each time one lane steps.  A run is stored by where it
-// sits in the particle's flattened candidate sequence: candidates [qend[k-1], qend[k]) are run k, and candidate q
-// of run k is sorted slot shift[k] + q.
+// sits in the particle's flattened candidate sequence: positions [qend[k-1], qend[k]) are run k (padded to a multiple
+// of kAhead), and position q of run k is sorted slot shift[k] + q.
 // QE: int where the whole stencil is walked whatever its size (search, density); unsigned short in the force pass, which
 // consults the table only for stencils of at most kMaskBits candidates and wants the LDS for a record tile.
 template <class QE>
@@ -144,7 +148,7 @@ __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ 
     const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
     const int len = inside ? e[k] - b[k] : 0;
     rt.shift[k][threadIdx.x] = b[k] - q;
-    q += len;
+    q += (len + kAhead - 1) / kAhead * kAhead;  // the mask pads every run to whole trips of the search
     trips += (len + kAhead - 1) / kAhead;
     rt.qend[k][threadIdx.x] = sizeof(QE) == 2 ? (QE)(q < 65535 ? q : 65535) : (QE)q;
   }
@@ -162,41 +166,106 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 // ---- neighbour search ---------------------------------------------------------------------------------------------
 // The only kernel that tests distances.  One lane per particle walks its flattened stencil four candidates per
 // trip (three independent 16-byte gathers in flight) and packs the outcomes into the particle's mask:
-// bit q <=> the q-th candidate passes sqrtf(r2) <= h, tested as r2 <= r2_max with
+// bit 4t + u <=> candidate u of trip t passes sqrtf(r2) <= h, tested as r2 <= r2_max with
 // r2 = (dx*dx + dy*dy) + dz*dz in uncontracted fp32 (:140-144).
 // WITH_DENSITY (fast arithmetic): the density is accumulated on the spot, rho_i = (m c_poly6)_fp32 * sum over the
 // neighbours of (h2 - r2)^3 (:65-68,:146 with r2 in place of the re-squared rounded r; no square root, no double
 // product), and written with its refined reciprocal into the particle's record: no separate density pass.
+//
+// The kernel is bound by the issue of its own instructions (switching the gathers or the distance arithmetic off
+// barely shortens it), so the loop is built to need few of them:
+//  * the search has a run table of its own (fill_search_runs): non-empty runs only, as (byte offset of the first
+//    position, length); the entry after the current run is fetched from LDS when the current one is entered, so stepping
+//    from run to run is a few register moves and never waits;
+//  * trip t fills bits 4t .. 4t+3: word index and shift are the same for every lane of the wave (no per-lane word
+//    bookkeeping, stores of completed words are uniform and coalesced);
+//  * a candidate past the end of its run gets a squared distance nothing passes, which serves the outcome bit and the
+//    density term alike.
+constexpr int kSearchRuns = 10;  // nine runs and a zero-length entry behind the last
+struct SearchRuns {
+  unsigned (*boff)[kBlock];  // byte offset of the run's first packed position
+  int (*len)[kBlock];        // candidates in the run
+};
+// Returns the number of kAhead-wide trips the particle's stencil takes.  *tight is set when fewer than kAhead - 1
+// slots lie between the end of one of the particle's runs and the start of its next one (or the end of the sorted
+// array): only then can a slot fetched past the end of a run be a particle that is ALSO a candidate of a later run (or
+// no particle at all).  Everywhere else the slots behind a run belong to cells outside the 27-cell stencil, at least
+// one padded cell away, and fail the distance test by themselves.
+__device__ inline int fill_search_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
+                                       const SearchRuns& rt, int n, bool* tight) {
+  const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
+  int b[9], e[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {  // branch-free: all 18 loads are issued before the first is waited for
+    const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
+    const int xc = x < 0 ? 0 : (x > P.nx - 1 ? P.nx - 1 : x), yc = y < 0 ? 0 : (y > P.ny - 1 ? P.ny - 1 : y);
+    const int row = (xc * P.ny + yc) * P.nz;
+    b[k] = start[row + z0];
+    e[k] = start[row + z1 + 1];
+  }
+  int nrun = 0, trips = 0, last_end = -kAhead;
+  bool close = false;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
+    const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
+    const int len = inside ? e[k] - b[k] : 0;
+    if (len > 0) {
+      rt.boff[nrun][threadIdx.x] = (unsigned)b[k] * 12u;  // a context holds far fewer than 2^32 / 12 particles
+      rt.len[nrun][threadIdx.x] = len;
+      nrun++;
+      trips += (len + kAhead - 1) / kAhead;
+      close = close || b[k] - last_end < kAhead - 1;  // runs are met in ascending slot order
+      last_end = e[k];
+    }
+  }
+  rt.boff[nrun][threadIdx.x] = 0u;
+  rt.len[nrun][threadIdx.x] = 0;
+  *tight = close || n - last_end < kAhead - 1;
+  return trips;
+}
+
 template <bool WITH_DENSITY>
 __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ cell_s, NeighbourMask nm,
-                                                       int32_t* __restrict__ ncount) {
-  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];
+                                                       int32_t* __restrict__ ncount, int n) {
+  __shared__ unsigned rt_boff[kSearchRuns][kBlock];
+  __shared__ int rt_len[kSearchRuns][kBlock];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
   const int off = range_first_slot(hi - lo, kBlock, P.dens_hi - P.dens_lo);
   const int s = lo + off + threadIdx.x;
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
-  const int trips = fill_runs(P, start, decode_cell(P, cell_s[s]), RunTable{rt_shift, rt_qend});
+  bool tight;
+  const int trips = fill_search_runs(P, start, decode_cell(P, cell_s[s]), SearchRuns{rt_boff, rt_len}, n, &tight);
+  // One wave, one loop: with the checks of run ends only if some lane of the wave needs them (a wave of the bulk of a
+  // fluid does not).
+  const bool check_ends = __any(tight);
+  constexpr float kFar = 3.0e38f;  // squared distance of a candidate past the end of its run
   unsigned word = 0;
-  int q = 0, cnt = 0;  // q: candidates seen so far = index of the next one in the flattened stencil
+  int cnt = 0;
   float sum = 0.0f;
   float dx, dy, dz;
+  // current run: byte offset of the next candidate and candidates left (<= 0: enter the next run); the run after it
+  int k = 0, rem = 0, len_n = rt_len[0][threadIdx.x];
+  unsigned boff = 0, boff_n = rt_boff[0][threadIdx.x];
+  uint32_t* wp = nm.words + s;  // where the word being assembled goes
   // the number of trips is known up front, so the loop needs no end-of-stencil test: a trip always finds a run
-  int k = -1, shift = 0, qe = 0;  // current run, its slot shift, its end in q
+  auto walk = [&](auto checked) {
   for (int t = 0; t < trips; t++) {
-    while (q >= qe) {  // next non-empty run
+    if (rem <= 0) {
+      boff = boff_n;
+      rem = len_n;
       ++k;
-      shift = rt_shift[k][threadIdx.x];
-      qe = rt_qend[k][threadIdx.x];
+      boff_n = rt_boff[k][threadIdx.x];
+      len_n = rt_len[k][threadIdx.x];
     }
-    const int m = qe - q < kAhead ? qe - q : kAhead;
     // Always fetch kAhead consecutive slots from one base address: past the end of the run they belong to the
-    // next cell or to the array's padding, and their outcomes are masked off below.
+    // next cell or to the array's padding, and they are kept out below.
     // kAhead = 4 packed positions are 48 bytes: three 16-byte loads (dword-aligned, as global loads may be), addressed
-    // by a 32-bit byte offset from the array's base (a context holds far fewer than 2^32 / 12 particles)
-    const Quad* base = reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(st.pos3) + (unsigned)(shift + q) * 12u);
+    // by a 32-bit byte offset from the array's base
+    const Quad* base = reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(st.pos3) + boff);
     const Quad w0 = base[0], w1 = base[1], w2 = base[2];
     float4 cand[kAhead];
     cand[0] = make_float4(w0.a, w0.b, w0.c, 0.0f);
@@ -205,32 +274,36 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
     cand[3] = make_float4(w2.b, w2.c, w2.d, 0.0f);
     float r2[kAhead];
 #pragma unroll
-    for (int u = 0; u < kAhead; u++) r2[u] = dist2_to(pi, cand[u], dx, dy, dz);
-    // outcomes shifted in from the last candidate to the first, one add-with-carry each: bit u <=> candidate u passes
+    for (int u = 0; u < kAhead; u++) {
+      r2[u] = dist2_to(pi, cand[u], dx, dy, dz);
+      if (decltype(checked)::value && u > 0) r2[u] = u < rem ? r2[u] : kFar;  // candidate 0 always belongs to the run
+    }
     unsigned bits = 0;
 #pragma unroll
     for (int u = kAhead - 1; u >= 0; u--) bits = bits + bits + (r2[u] <= P.r2_max ? 1u : 0u);
     if (WITH_DENSITY) {
-      // (h2 - r2) clamped at 0 in the subtraction itself: a candidate beyond h adds nothing, and one beyond the end of
-      // the run is kept out by the limit it is compared with
+      // (h2 - r2) clamped at 0 in the subtraction itself: a candidate beyond h (or beyond its run) adds nothing
 #pragma unroll
       for (int u = 0; u < kAhead; u++) {
-        const float d = __builtin_amdgcn_fmed3f(P.h2 - (u < m ? r2[u] : P.h2), 0.0f, 1.0f);
+        const float d = __builtin_amdgcn_fmed3f(P.h2 - r2[u], 0.0f, 1.0f);
         sum = __builtin_fmaf(d * d, d, sum);
       }
     }
-    bits &= (1u << m) - 1u;
     cnt += __popc(bits);
-    const int sh = q & 31;
-    word |= bits << sh;
-    q += m;
-    if (sh + m >= 32) {  // the current word is complete; bits past it start the next one
-      if ((q >> 5) <= kMaskWords) nm.words[(size_t)((q >> 5) - 1) * nm.stride + s] = word;
-      word = sh + m > 32 ? bits >> (32 - sh) : 0u;
+    word |= bits << ((t & 7) * kAhead);
+    if ((t & 7) == 7) {  // uniform: the word is complete for every lane still walking
+      if ((t >> 3) < kMaskWords) *wp = word;
+      wp += nm.stride;
+      word = 0;
     }
+    boff += 12u * kAhead;
+    rem -= kAhead;
   }
-  if ((q & 31) != 0 && (q >> 5) < kMaskWords) nm.words[(size_t)(q >> 5) * nm.stride + s] = word;
-  nm.ncand[s] = q;
+  };
+  if (check_ends) walk(std::true_type{});
+  else walk(std::false_type{});
+  if ((trips & 7) != 0 && (trips >> 3) < kMaskWords) *wp = word;
+  nm.ncand[s] = trips * kAhead;
   nm.nnb[s] = cnt;
   if (WITH_DENSITY) {
     const float rho = P.k_dens * sum;
@@ -562,9 +635,9 @@ void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int
   if (n <= 0) return;
   const DevParams& P = P0;
   if (with_density)
-    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount);
+    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount, n);
   else
-    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount);
+    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount, n);
 }
 
 void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
