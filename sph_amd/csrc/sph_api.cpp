@@ -222,6 +222,8 @@ void derive(const sph_params* p, int nx, int cx_off, int gn, DevParams* d) {
   d->nx = nx;
   d->ny = gn;
   d->nz = gn;
+  division_constants((uint32_t)d->ny, &d->ny_mul, &d->ny_shift);
+  division_constants((uint32_t)d->nz, &d->nz_mul, &d->nz_shift);
   d->cx_off = cx_off;
   d->gnx = gn;
   d->tension = (p->flags & SPH_FLAG_SURFACE_TENSION) ? 1 : 0;

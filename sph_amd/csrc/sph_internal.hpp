@@ -19,6 +19,9 @@ struct DevParams {
   float gx, gy, gz, dt, tank, neg_sigma;
   float cell;                // cell edge
   int nx, ny, nz;            // cells per axis of the local grid
+  // c / ny and c / nz for 0 <= c < 2^31 as a multiply-high and a shift (division_constants()); unused when the
+  // divisor is 1
+  uint32_t ny_mul, ny_shift, nz_mul, nz_shift;
   int cx_off;                // global x-column of local column 0 (slab decomposition)
   int gnx;                   // global cells per axis (for clamping before the offset)
   int own_lo, own_hi;        // local x-columns this context integrates: [own_lo, own_hi)
@@ -35,6 +38,15 @@ struct DevParams {
   float k_tlapl;             // m * c_poly6_lapl                 colour laplacian, :92,:252
   float c2rho0;              // c2 * rho0
 };
+
+// Constants that turn c / d, 0 <= c < 2^31, d >= 2, into (uint32)(((uint64)c * mul) >> 32) >> shift: with
+// s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1 fits 32 bits and overshoots 2^(31+s) / d by less than 2^-31 of it.
+inline void division_constants(uint32_t d, uint32_t* mul, uint32_t* shift) {
+  uint32_t s = 0;
+  while ((1ull << s) < d) s++;
+  *mul = d < 2 ? 0u : (uint32_t)(((1ull << (31 + s)) / d) + 1);
+  *shift = d < 2 ? 0u : s - 1;
+}
 
 // Structure-of-arrays particle state in HBM.
 struct State {

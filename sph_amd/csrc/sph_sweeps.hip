@@ -58,11 +58,24 @@ __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); 
 // time to imbalance).  Bijective for any grid size (the tail that does not fill 8 runs keeps its index);
 // affects locality only, never results.
 constexpr int kXcdWindows = 8;
+// a / b for 0 <= a, b < 2^24, b >= 1 (block counts): float reciprocal and corrections instead of the ~30 instructions
+// of a general 32-bit division - every lane computes these block-uniform values.  The estimate is within 2^-22 of
+// a / b relatively, i.e. at most 2 off the quotient either way after rounding and truncation.
+__device__ inline int div_small(int a, int b) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  int r = a - q * b;
+  if (r < 0) { q--; r += b; }
+  if (r < 0) { q--; r += b; }
+  if (r >= b) { q++; r -= b; }
+  if (r >= b) q++;
+  return q;
+}
 __device__ inline int xcd_block(int b, int nb, int run) {
   const int span = 8 * run;
-  if (b >= nb / span * span) return b;
+  if (b >= div_small(nb, span) * span) return b;
   const int xcd = b & 7, i = b >> 3;
-  return ((i / run) * 8 + xcd) * run + i % run;
+  const int w = div_small(i, run);
+  return (w * 8 + xcd) * run + (i - w * run);
 }
 
 // First slot offset of this block within a range of `nslots` slots that a launch of at least ceil(nslots / B) blocks
@@ -75,9 +88,11 @@ __device__ inline int xcd_block(int b, int nb, int run) {
 __device__ inline int range_first_slot(int nslots, int B, int ncols) {
   const int nact = (nslots + B - 1) / B;
   if ((int)blockIdx.x >= nact) return -1;
-  int windows = ncols / 24;
-  windows = windows < 1 ? 1 : (windows > kXcdWindows ? kXcdWindows : windows);
-  int run = nact / (8 * windows);
+  // ncols / 24 below 24 * kXcdWindows columns: (ncols * 171) >> 12 is exact up to 192
+  static_assert(kXcdWindows == 8, "the multiply-shift below stands for ncols / 24 up to 24 * 8 columns");
+  int windows = ncols >= 24 * kXcdWindows ? kXcdWindows : (ncols * 171) >> 12;
+  windows = windows < 1 ? 1 : windows;
+  int run = div_small(nact, 8 * windows);
   run = run > 0 ? run : 1;
   return xcd_block(blockIdx.x, nact, run) * B;
 }
@@ -85,12 +100,17 @@ __device__ inline int range_first_slot(int nslots, int B, int ncols) {
 struct CellCoord {
   int x, y, z;
 };
+// Two divisions by grid dimensions per particle and pass: by multiply-high and shift with constants from the host
+// (an integer division by a run-time divisor is some 35 vector instructions on this chip).
+__device__ inline int div_by_dim(int c, int d, uint32_t mul, uint32_t shift) {
+  return d == 1 ? c : (int)(__umulhi((uint32_t)c, mul) >> shift);
+}
 __device__ inline CellCoord decode_cell(const DevParams& P, int c) {
   CellCoord q;
-  q.z = c % P.nz;
-  int t = c / P.nz;
-  q.y = t % P.ny;
-  q.x = t / P.ny;
+  const int t = div_by_dim(c, P.nz, P.nz_mul, P.nz_shift);
+  q.z = c - t * P.nz;
+  q.x = div_by_dim(t, P.ny, P.ny_mul, P.ny_shift);
+  q.y = t - q.x * P.ny;
   return q;
 }
 
