@@ -17,8 +17,6 @@
 //   k_density     walks the set bits: every loop trip is a true neighbour, so the sqrt / double-precision
 //                 kernel arithmetic runs with the wave's lanes busy instead of ~20 % of them;
 //   k_force       same walk with the pair arithmetic of :153-262, then Euler step and wall reflection.
-// In the force pass the 256 particles of a block are handed to lanes in order of decreasing neighbour count, so
-// the lanes of a wave (which run in lockstep) carry similar loads.
 //
 // Other flavours, for verification and ablation:
 //   SWEEP_PLAIN  tests and evaluates in one loop (no mask); same results bit for bit as SWEEP_MASKED;
@@ -230,14 +228,13 @@ __device__ inline int fill_search_runs(const DevParams& P, const int32_t* __rest
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
     const bool inside = x >= 0 && x < P.nx && y >= 0 && y < P.ny;
     const int len = inside ? e[k] - b[k] : 0;
-    if (len > 0) {
-      rt.boff[nrun][threadIdx.x] = (unsigned)b[k] * 12u;  // a context holds far fewer than 2^32 / 12 particles
-      rt.len[nrun][threadIdx.x] = len;
-      nrun++;
-      trips += (len + kAhead - 1) / kAhead;
-      close = close || b[k] - last_end < kAhead - 1;  // runs are met in ascending slot order
-      last_end = e[k];
-    }
+    // branch-free: an empty run's entry is written too and overwritten by the next run's (or by the closing entry)
+    rt.boff[nrun][threadIdx.x] = (unsigned)b[k] * 12u;  // a context holds far fewer than 2^32 / 12 particles
+    rt.len[nrun][threadIdx.x] = len;
+    nrun += len > 0 ? 1 : 0;
+    trips += (len + kAhead - 1) / kAhead;
+    close = close || (len > 0 && b[k] - last_end < kAhead - 1);  // runs are met in ascending slot order
+    last_end = len > 0 ? e[k] : last_end;
   }
   rt.boff[nrun][threadIdx.x] = 0u;
   rt.len[nrun][threadIdx.x] = 0;
@@ -333,42 +330,12 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   }
 }
 
-// Lanes of a wave run in lockstep, so a wave takes as long as its particle with the most neighbours.  The force
-// pass hands the block's particles to lanes in order of decreasing neighbour count, in bins of eight (counting
-// sort in LDS), so that every wave gets particles of similar load.  Inside a bin the particles keep their slot
-// order - the waves take their ranks one after the other - because neighbours in slot order are neighbours in
-// space and share cache lines; an order that ignores this costs more in L1 misses than the balancing gains
-// (measured: the density pass, whose trips are short, runs 10 % faster with no reordering at all and does none).
-// Which lane advances which particle has no influence on any result.
-// Returns the index within the block that this lane takes.
-constexpr int kLoadBins = 64;  // bin b: 8b .. 8b+7 neighbours; the last bin is open-ended
-__device__ inline int lane_by_count(int k) {  // k: this lane's neighbour count, -1 for a lane without a particle
-  __shared__ int bin_fill[kLoadBins + 2];
-  __shared__ unsigned short perm[kBlock];
-  const int bin = k < 0 ? kLoadBins : kLoadBins - 1 - (k >> 3 > kLoadBins - 1 ? kLoadBins - 1 : k >> 3);  // idle lanes last
-  for (int i = threadIdx.x; i <= kLoadBins; i += kBlock) bin_fill[i] = 0;
-  __syncthreads();
-  int rank = 0;
-  for (int w = 0; w < kBlock / 64; w++) {  // wave after wave, so that ranks inside a bin follow the slot order
-    if ((int)(threadIdx.x >> 6) == w) rank = atomicAdd(&bin_fill[bin], 1);
-    __syncthreads();
-  }
-  if (threadIdx.x < 64) {  // first wave: exclusive prefix sum over bins 0..63, the idle-lane bin after them
-    const int c = bin_fill[threadIdx.x];
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(incl, d, 64);
-      if ((int)threadIdx.x >= d) incl += up;
-    }
-    bin_fill[threadIdx.x] = incl - c;
-    if (threadIdx.x == 63) bin_fill[kLoadBins] = incl;
-  }
-  __syncthreads();
-  perm[bin_fill[bin] + rank] = (unsigned short)threadIdx.x;
-  __syncthreads();
-  return perm[threadIdx.x];
-}
+// Lanes of a wave run in lockstep, so a wave takes as long as its particle with the most neighbours.  Dealing the
+// block's particles to lanes by neighbour count (a counting sort in LDS, bins of eight) used to even that out; with the
+// kernels as they are it loses everywhere it was measured - consecutive slots per wave share more cache lines than equal
+// loads save, and the sort cost eight barriers per block: force pass 1.40 -> 1.27 ms on the 16.8M-particle cube,
+// 2.34 -> 2.16 ms on the 8M-particle dam break at its peak, 71 -> 69 us on the 1M dam break at rest density and
+// 198 -> 195 us at its peak.  The lanes of a block are its slots in order.
 
 // Walks the set bits of particle slot s's candidate mask in order and calls visit(pos_j, vel_j) for each; load(j,
 // pos, vel) fetches candidate index j, where j counts from the run starts in column `col` of the run table (slots
@@ -563,12 +530,11 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   }
   const int first = range_first_slot(bound - base, kBlock, P.force_hi - P.force_lo);
   if (first < 0) return;  // whole block beyond the range (uniform: before any barrier)
-  int col = threadIdx.x;
+  const int col = threadIdx.x;
   __shared__ float4 tile_pos[MODE == SWEEP_MASKED ? kTileRecords : 1], tile_vel[MODE == SWEEP_MASKED ? kTileRecords : 1];
   RecordTile tile{tile_pos, tile_vel, 0, 0u};
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
-    const int load = s_nat < bound ? nm.nnb[s_nat] : -1;
     if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTableT<unsigned short>{rt_shift, rt_qend});
     tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
     const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
@@ -577,7 +543,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
       tile_pos[t] = st.rec[tile.lo + t].pos;
       tile_vel[t] = st.rec[tile.lo + t].vel;
     }
-    col = lane_by_count(load);  // its barriers also publish the tile
+    __syncthreads();  // publishes the tile (every thread of the block gets here: the range test above is block-wide)
   }
   const int s = base + first + col;
   const int o = s - own_base;
