@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel stats + counters for the bench workload, over EXACTLY the window
-# bench.py times by default when the round driver calls it (pre-roll 60, --warmup 5, --steps 20).
+# bench.py times by default when the driver calls it (pre-roll 60, --warmup 5, --steps 20).
 # Each counter pass is its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).
 # usage: scripts/profile_on_gpu.sh <tag>      outputs under gpurun_out/prof_<tag>_{stats,fetch,write,sq,mix,ta}
 set -e
