@@ -311,10 +311,15 @@ void sph_oracle_cell_ids(const sph_params* p, const float* pos, int n, int32_t* 
   }
 }
 
-typedef struct { int32_t cell, id, idx; } key_t_;
+/* Order of the grid twin's sorted copy: by cell; inside a cell the particles in the lower half of the cell in z
+ * first, then those in the upper half; inside a half by particle id.  `half` is the low bit of the particle's
+ * coordinate on a grid of half the cell edge in z (x / (cell/2) = 2 (x / cell) exactly in fp32, so the two grids agree
+ * about every cell boundary).  The summation order of order 0 is this sorted order, run by run. */
+typedef struct { int32_t cell, half, id, idx; } key_t_;
 static int cmp_key(const void* a, const void* b) {
   const key_t_* x = (const key_t_*)a; const key_t_* y = (const key_t_*)b;
   if (x->cell != y->cell) return x->cell < y->cell ? -1 : 1;
+  if (x->half != y->half) return x->half < y->half ? -1 : 1;
   if (x->id != y->id) return x->id < y->id ? -1 : 1;
   return 0;
 }
@@ -367,7 +372,12 @@ void sph_oracle_step_grid(const sph_params* p, float* pos, float* vel, const int
   key_t_* keys = (key_t_*)malloc(((size_t)n + 1) * sizeof(key_t_));
   int32_t* cid = (int32_t*)malloc(((size_t)n + 1) * sizeof(int32_t));
   sph_oracle_cell_ids(p, pos, n, cid);
-  for (int i = 0; i < n; i++) { keys[i].cell = cid[i]; keys[i].id = ids ? ids[i] : i; keys[i].idx = i; }
+  for (int i = 0; i < n; i++) {
+    keys[i].cell = cid[i];
+    keys[i].half = cell_coord(pos[3 * i + 2], c.k.cell_size * 0.5f, 2 * nc) & 1;
+    keys[i].id = ids ? ids[i] : i;
+    keys[i].idx = i;
+  }
   qsort(keys, (size_t)n, sizeof(key_t_), cmp_key);
 
   float* spos = (float*)malloc(((size_t)n * 3 + 1) * sizeof(float));

@@ -281,6 +281,7 @@ int layout_step_buffers(Source& src, sph_context* c, size_t n, size_t ncells) {
   c->nmask.stride = n;
   const size_t padded = padded_cells(ncells);
   if ((rc = dev_alloc(src, &c->grid.count, padded)) || (rc = dev_alloc(src, &c->grid.start, padded + 4)) ||
+      (rc = dev_alloc(src, &c->grid.mid, padded + 4)) ||
       (rc = dev_alloc(src, &c->grid.block_sums, padded / kScanItems + 1)) || (rc = dev_alloc(src, &c->grid.cell_of, n)) ||
       (rc = dev_alloc(src, &c->grid.rank_of, n)) || (rc = dev_alloc(src, &c->grid.src_of, n)) ||
       (rc = dev_alloc(src, &c->grid.id_prov, n)) || (rc = dev_alloc(src, &c->grid.cell_s, n)))
@@ -507,7 +508,8 @@ int sph_destroy(sph_context* c) {
   free_state(&c->cur);
   (void)hipFree(c->sorted.pos3); (void)hipFree(c->sorted.rec); (void)hipFree(c->sorted.id);
   (void)hipFree(c->nmask.words); (void)hipFree(c->nmask.ncand); (void)hipFree(c->nmask.nnb);
-  (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.block_sums);
+  (void)hipFree(c->grid.count); (void)hipFree(c->grid.start); (void)hipFree(c->grid.mid);
+  (void)hipFree(c->grid.block_sums);
   (void)hipFree(c->grid.cell_of); (void)hipFree(c->grid.rank_of); (void)hipFree(c->grid.src_of);
   (void)hipFree(c->grid.id_prov); (void)hipFree(c->grid.cell_s);
   (void)hipFree(c->dbg.force); (void)hipFree(c->dbg.ncount);
@@ -1772,7 +1774,7 @@ int sph_host_unregister(void* p) {
 constexpr size_t kNoAllocCells = (size_t)SPH_NOALLOC_MAX_CELLS + 1;  // + trash cell
 constexpr size_t kNoAllocPerParticle =
     7 * 4 + sizeof(float4) + sizeof(ParticleRec) + 4 + (size_t)(kMaskWords + 2) * 4 + 2 * 4 + 5 * 4;
-constexpr size_t kNoAllocPerCell = 2 * sizeof(int32_t);
+constexpr size_t kNoAllocPerCell = 3 * sizeof(int32_t);
 constexpr size_t kScratchBytes = kNoAllocPerParticle * SPH_NOALLOC_MAX_PARTICLES +
                                  kNoAllocPerCell * (kNoAllocCells + 2 * kScanItems) + 64 * 1024;  // + alignment slack
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];

@@ -16,6 +16,14 @@ __device__ inline int cell_coord(float x, float cell, int gn) {
   return (int)q;
 }
 
+// 1 if z lies in the upper half of its cell (in z), 0 in the lower.  x / (cell/2) = 2 (x / cell) exactly in fp32 (a
+// power of two commutes with rounding), so this is the low bit of floor(2 q) for the very q whose floor is the cell
+// coordinate: the two never disagree about which cell the halves belong to, clamps included.
+// Sorting a cell's particles lower half first lets a particle leave out the far half of the cell beyond its own half:
+// a particle in the lower half of cell cz and one in the upper half of cell cz + 1 are more than one padded cell edge
+// minus half an ulp of the quotient apart, the same margin that keeps cells two apart from interacting.
+__device__ inline int upper_half(const DevParams& P, float z) { return cell_coord(z, P.cell * 0.5f, 2 * P.nz) & 1; }
+
 __device__ inline float dist2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }  // :143
 // Grid-sorted position of slot j (w = 0).
 __device__ inline float4 sorted_pos(const Sorted& st, int j) {

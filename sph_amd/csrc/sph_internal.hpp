@@ -87,6 +87,8 @@ struct GridBuffers {
   // ncells counts the real cells PLUS one trailing trash cell for particles outside the local grid.
   int32_t* count;      // [ncells]   histogram, left zeroed by the scan
   int32_t* start;      // [ncells+1] exclusive prefix sum: cell c owns slots [start[c], start[c+1])
+  int32_t* mid;        // [ncells]   first slot of cell c's particles in the upper half of the cell in z: inside a cell
+                       //            the lower half comes first (ascending id), then the upper half (ascending id)
   int32_t* block_sums; // scan scratch
   int32_t* cell_of;    // [n] cell of particle i (pre-sort order)
   int32_t* rank_of;    // [n] arrival rank of particle i in its cell (arbitrary, from the atomic)

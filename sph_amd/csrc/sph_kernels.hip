@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, i
   cnt[lane] = 0; cnt[lane + 64] = 0;
   const bool valid = i < n;
   int c = -1 - lane;  // lanes without a particle: distinct keys, never entered
+  int upper = 0;      // which half of its cell (in z) the particle is in: bit 31 of its rank word
   if (valid) {
     // A particle whose x-column lies outside this context's local grid (possible only in slab mode) goes to
     // the trash cell appended after the last real cell: it sorts behind everything and no pass visits it.
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, i
     const int cy = cell_coord(in.y[i], P.cell, P.ny);
     const int cz = cell_coord(in.z[i], P.cell, P.nz);
     c = (cx < 0 || cx >= P.nx) ? P.nx * P.ny * P.nz : (cx * P.ny + cy) * P.nz + cz;
+    upper = upper_half(P, in.z[i]);
   }
   const int prev = __shfl_up(c, 1, 64);
   const bool head = lane == 0 || prev != c;
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) k_hash(DevParams P, State in, int n, i
   local = __shfl(local, head_lane, 64);
   if (valid) {
     cell_of[i] = c;
-    rank_of[i] = cnt[at] + local + lane - head_lane;
+    rank_of[i] = (cnt[at] + local + lane - head_lane) | (upper << 31);
   }
 }
 
@@ -198,7 +200,8 @@ __global__ void __launch_bounds__(kBlock) k_scan_top(int32_t* __restrict__ block
 constexpr int kFusedTopBlocks = 2048;
 __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ count, size_t ncells,
                                                        const int32_t* __restrict__ block_sums,
-                                                       int32_t* __restrict__ start, int sums_are_raw) {
+                                                       int32_t* __restrict__ start, int32_t* __restrict__ mid,
+                                                       int sums_are_raw) {
   size_t base = (size_t)blockIdx.x * kScanItems + (size_t)threadIdx.x * kPerThread;
   int v[kPerThread];
   int s = 0;
@@ -236,8 +239,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ cou
     before = block_sums[blockIdx.x];
   }
   int run = before + block_exclusive_scan(s, &tot);
+  // mid[] starts out equal to start[]: k_reorder overwrites the entries of the cells that hold particles
   if (full) {
     int4* o = reinterpret_cast<int4*>(start + base);
+    int4* om = reinterpret_cast<int4*>(mid + base);
 #pragma unroll
     for (int k = 0; k < kPerThread / 4; k++) {
       int4 q;
@@ -246,11 +251,15 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(int32_t* __restrict__ cou
       q.z = run; run += v[4 * k + 2];
       q.w = run; run += v[4 * k + 3];
       o[k] = q;
+      om[k] = q;
     }
   } else {
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
-      if (base + k < ncells) start[base + k] = run;
+      if (base + k < ncells) {
+        start[base + k] = run;
+        mid[base + k] = run;
+      }
       run += v[k];
     }
   }
@@ -268,40 +277,49 @@ __global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int3
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = cell_of[i];
-  const int slot = start[c] + rank_of[i];
+  const int rw = rank_of[i];  // bit 31: upper half of the cell
+  const int slot = start[c] + (rw & 0x7fffffff);
   src_of[slot] = i;
-  id_prov[slot] = id_in[i];
+  id_prov[slot] = id_in[i] | (rw & (int)0x80000000u);  // ids are below 2^31: the sort key is (half, id)
   cell_s[slot] = c;
 }
 
-// Final slot = cell start + number of cell-mates with a smaller id: the in-cell order no longer depends
-// on the order in which the histogram atomics happened to be served.  The lanes of a wave are consecutive slots,
-// hence mostly cell-mates that count over the same ids: those loads are one request per wave.
-__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ start,
+// Final slot = cell start + number of cell-mates with a smaller key, the key being (half of the cell in z, id): the
+// in-cell order no longer depends on the order in which the histogram atomics happened to be served.  The lanes of a
+// wave are consecutive slots, hence mostly cell-mates that count over the same keys: those loads are one request per
+// wave.  The cell's first particle in the new order also records where the cell's upper half begins.
+__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ start, int32_t* __restrict__ mid,
                           const int32_t* __restrict__ src_of, const int32_t* __restrict__ id_prov,
                           const int32_t* __restrict__ cell_s) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const int i = src_of[s];
-  const int my = id_prov[s];
+  const unsigned my = (unsigned)id_prov[s];
   const int c = cell_s[s];
   const int b = start[c], e = start[c + 1];
   const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
   const float4 vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);
-  int r = 0;
+  int r = 0, uppers = 0;
   int t = b;
   for (; t + 4 <= e; t += 4) {  // four independent loads per trip
-    const int a0 = id_prov[t], a1 = id_prov[t + 1], a2 = id_prov[t + 2], a3 = id_prov[t + 3];
+    const unsigned a0 = (unsigned)id_prov[t], a1 = (unsigned)id_prov[t + 1], a2 = (unsigned)id_prov[t + 2],
+                   a3 = (unsigned)id_prov[t + 3];
     r += (a0 < my) + (a1 < my) + (a2 < my) + (a3 < my);
+    uppers += (int)((a0 >> 31) + (a1 >> 31) + (a2 >> 31) + (a3 >> 31));
   }
-  for (; t < e; t++) r += id_prov[t] < my;
+  for (; t < e; t++) {
+    const unsigned a = (unsigned)id_prov[t];
+    r += a < my;
+    uppers += (int)(a >> 31);
+  }
   const int d = b + r;
+  if (r == 0) mid[c] = e - uppers;
   out.pos3[3 * (size_t)d + 0] = pos.x;
   out.pos3[3 * (size_t)d + 1] = pos.y;
   out.pos3[3 * (size_t)d + 2] = pos.z;
   out.rec[d].pos = pos;  // w receives 1/density
   out.rec[d].vel = vel;  // w receives the density
-  out.id[d] = my;
+  out.id[d] = (int)(my & 0x7fffffffu);
 }
 
 // ---- slab decomposition: halo/migration records ---------------------------------------------------------------
@@ -598,7 +616,7 @@ void launch_scan(hipStream_t s, GridBuffers g) {
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums);
   const bool fused = nb <= kFusedTopBlocks;
   if (!fused) hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, g.block_sums, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start,
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kBlock), 0, s, g.count, g.ncells, g.block_sums, g.start, g.mid,
                      fused ? 1 : 0);
 }
 
@@ -606,8 +624,8 @@ void launch_reorder(hipStream_t s, const State& in, const Sorted& out, int n, Gr
   if (n <= 0) return;
   hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, g.cell_of, g.rank_of, g.start,
                      in.id, g.src_of, g.id_prov, g.cell_s);
-  hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.start, g.src_of, g.id_prov,
-                     g.cell_s);
+  hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, in, out, g.start, g.mid, g.src_of,
+                     g.id_prov, g.cell_s);
 }
 
 void launch_slab_pack(hipStream_t s, const DevParams& P, const State& st, int n, const int32_t* n_dev, int col_lo,

@@ -5,7 +5,8 @@
 // position (search, density) and a 32-byte record with position and velocity + density (force).  Cells are
 // linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the slab axis, slowest): the 27-cell stencil of a
 // particle is 9 runs of up to 3 z-adjacent cells, each run ONE contiguous slot range.  Runs are visited
-// dx-major, dy-minor; inside a cell particles are in ascending id order.  That order is a pure function of
+// dx-major, dy-minor; inside a cell the particles of its lower half in z come first, then those of its upper half, each
+// half in ascending id order (so a run can leave out the half of an end cell that is out of the particle's reach).  That order is a pure function of
 // (positions, ids), so results do not depend on how particles share waves, blocks, contexts or slabs.
 //
 // Default (SWEEP_MASKED) pipeline, one lane per particle in every kernel:
@@ -144,10 +145,39 @@ struct RunTableT {
 };
 using RunTable = RunTableT<int>;
 // Returns the number of kAhead-wide trips a walk over all runs takes.
+// Where a stencil run of a particle in cell (.., .., cz) begins and ends in a row of cells, as (table, index) pairs: the
+// cells cz-1 .. cz+1, minus the half of an end cell that the particle's own half of its cell puts out of reach (the
+// lower half of cz-1 for a particle in the upper half of cz, the upper half of cz+1 for one in the lower half; a
+// cell's particles are sorted lower half first and mid[] is where its upper half begins).
+struct RunEnds {
+  const int32_t* first_table;
+  const int32_t* last_table;
+  int first, last;  // cell offsets within a row: the run is [first_table[row + first], last_table[row + last])
+};
+// Only particles of well-filled cells clip their runs (kClipFrom particles or more in the particle's own cell, which
+// every pass can read off the start table): the lanes of a cell then fall into two groups with different runs, and
+// where cells hold three particles that costs the vector cache more merged lookups than the shorter runs save.
+#ifndef SPH_CLIP_FROM
+#define SPH_CLIP_FROM 8
+#endif
+constexpr int kClipFrom = SPH_CLIP_FROM;
+__device__ inline RunEnds run_ends(const DevParams& P, const int32_t* __restrict__ start,
+                                   const int32_t* __restrict__ mid, int cell, int cz, int upper) {
+  RunEnds r;
+  const bool clip = start[cell + 1] - start[cell] >= kClipFrom;
+  r.first_table = (clip && upper && cz > 0) ? mid : start;
+  r.first = cz > 0 ? cz - 1 : 0;
+  const bool clip_top = clip && !upper && cz < P.nz - 1;
+  r.last_table = clip_top ? mid : start;
+  r.last = clip_top ? cz + 1 : (cz < P.nz - 1 ? cz + 2 : P.nz);
+  return r;
+}
+
 template <class QE>
-__device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
+__device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start,
+                                const int32_t* __restrict__ mid, const CellCoord cc, int upper,
                                 const RunTableT<QE>& rt) {
-  const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
+  const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
   // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
   // no branch, so that all 18 loads are issued before the first is waited for
   int b[9], e[9];
@@ -156,8 +186,8 @@ __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ 
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
     const int xc = x < 0 ? 0 : (x > P.nx - 1 ? P.nx - 1 : x), yc = y < 0 ? 0 : (y > P.ny - 1 ? P.ny - 1 : y);
     const int row = (xc * P.ny + yc) * P.nz;
-    b[k] = start[row + z0];
-    e[k] = start[row + z1 + 1];
+    b[k] = re.first_table[row + re.first];
+    e[k] = re.last_table[row + re.last];
   }
   int q = 0, trips = 0;
 #pragma unroll
@@ -209,17 +239,18 @@ struct SearchRuns {
 // array): only then can a slot fetched past the end of a run be a particle that is ALSO a candidate of a later run (or
 // no particle at all).  Everywhere else the slots behind a run belong to cells outside the 27-cell stencil, at least
 // one padded cell away, and fail the distance test by themselves.
-__device__ inline int fill_search_runs(const DevParams& P, const int32_t* __restrict__ start, const CellCoord cc,
+__device__ inline int fill_search_runs(const DevParams& P, const int32_t* __restrict__ start,
+                                       const int32_t* __restrict__ mid, const CellCoord cc, int upper,
                                        const SearchRuns& rt, int n, bool* tight) {
-  const int z0 = cc.z > 0 ? cc.z - 1 : 0, z1 = cc.z < P.nz - 1 ? cc.z + 1 : P.nz - 1;
+  const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
   int b[9], e[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {  // branch-free: all 18 loads are issued before the first is waited for
     const int x = cc.x + k / 3 - 1, y = cc.y + k % 3 - 1;
     const int xc = x < 0 ? 0 : (x > P.nx - 1 ? P.nx - 1 : x), yc = y < 0 ? 0 : (y > P.ny - 1 ? P.ny - 1 : y);
     const int row = (xc * P.ny + yc) * P.nz;
-    b[k] = start[row + z0];
-    e[k] = start[row + z1 + 1];
+    b[k] = re.first_table[row + re.first];
+    e[k] = re.last_table[row + re.last];
   }
   int nrun = 0, trips = 0, last_end = -kAhead;
   bool close = false;
@@ -244,6 +275,7 @@ __device__ inline int fill_search_runs(const DevParams& P, const int32_t* __rest
 
 template <bool WITH_DENSITY>
 __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ mid,
                                                        const int32_t* __restrict__ cell_s, NeighbourMask nm,
                                                        int32_t* __restrict__ ncount, int n) {
   __shared__ unsigned rt_boff[kSearchRuns][kBlock];
@@ -255,7 +287,8 @@ __global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, c
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   bool tight;
-  const int trips = fill_search_runs(P, start, decode_cell(P, cell_s[s]), SearchRuns{rt_boff, rt_len}, n, &tight);
+  const int trips = fill_search_runs(P, start, mid, decode_cell(P, cell_s[s]), upper_half(P, pi.z),
+                                     SearchRuns{rt_boff, rt_len}, n, &tight);
   // One wave, one loop: with the checks of run ends only if some lane of the wave needs them (a wave of the bulk of a
   // fluid does not).
   const bool check_ends = __any(tight);
@@ -444,6 +477,7 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
 // place of the re-squared rounded r - and 1/rho_i, refined, stored beside it for the force pass.
 template <int MODE, bool FAST>
 __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ mid,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
   __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
@@ -457,7 +491,8 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   const CellCoord cc = decode_cell(P, cell_s[s]);
-  if (MODE == SWEEP_MASKED) fill_runs(P, start, cc, RunTable{rt_shift, rt_qend});  // own column: no barrier needed
+  if (MODE == SWEEP_MASKED)  // own column: no barrier needed
+    fill_runs(P, start, mid, cc, upper_half(P, pi.z), RunTable{rt_shift, rt_qend});
   float acc = 0.0f;
   int cnt = 0;
   float dx, dy, dz;
@@ -514,6 +549,7 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
 template <int MODE, bool FAST>
 __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State out, int n,
                                                   const int32_t* __restrict__ start,
+                                                  const int32_t* __restrict__ mid,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
   __shared__ int rt_shift[9][kBlock];  // used by the masked flavour only
@@ -535,7 +571,9 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   RecordTile tile{tile_pos, tile_vel, 0, 0u};
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
-    if (s_nat < bound) fill_runs(P, start, decode_cell(P, cell_s[s_nat]), RunTableT<unsigned short>{rt_shift, rt_qend});
+    if (s_nat < bound)
+      fill_runs(P, start, mid, decode_cell(P, cell_s[s_nat]), upper_half(P, st.pos3[3 * (size_t)s_nat + 2]),
+                RunTableT<unsigned short>{rt_shift, rt_qend});
     tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
     const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
     tile.n = (unsigned)(tile_hi - tile.lo);
@@ -621,9 +659,9 @@ void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int
   if (n <= 0) return;
   const DevParams& P = P0;
   if (with_density)
-    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount, n);
+    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
   else
-    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.cell_s, nm, ncount, n);
+    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
 }
 
 void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
@@ -632,13 +670,13 @@ void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n,
   const DevParams& P = P0;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL((k_density<SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
   else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL((k_density<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
   else if (mode == SWEEP_FAST)
-    hipLaunchKernelGGL((k_density<SWEEP_MASKED, true>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_MASKED, true>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
   else
-    hipLaunchKernelGGL((k_density<SWEEP_MASKED, false>), grid, block, 0, s, P, st, g.start, g.cell_s, ncount, nm);
+    hipLaunchKernelGGL((k_density<SWEEP_MASKED, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
 }
 
 void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const State& out, int n,
@@ -648,13 +686,13 @@ void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const St
   const DevParams& P = P0;
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL((k_force<SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
   else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL((k_force<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
   else if (mode == SWEEP_FAST)
-    hipLaunchKernelGGL((k_force<SWEEP_MASKED, true>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_MASKED, true>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
   else
-    hipLaunchKernelGGL((k_force<SWEEP_MASKED, false>), grid, block, 0, s, P, st, out, n, g.start, g.cell_s, force_dbg, n_own_out, nm);
+    hipLaunchKernelGGL((k_force<SWEEP_MASKED, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
 }
 
 }  // namespace sph
