@@ -64,7 +64,8 @@ void sph_oracle_cell_ids(const sph_params* p, const float* pos, int n, int32_t* 
 /*
  * Uniform-grid twin: same physics restricted to the 27-cell stencil.
  *   order = 0: neighbours are summed in stencil order (dx,dy outer; cells ascending in z;
- *              ascending id inside a cell) — the order of the HIP fast path;
+ *              inside a cell the lower half in z before the upper half, ascending id inside a
+ *              half) — the order of the HIP fast path;
  *   order = 1: ascending particle id — bit-identical to sph_oracle_step_allpairs.
  * ids[n] may be NULL (id = index).  ncount_out (may be NULL) gets neighbour counts.
  * Not the reference algorithm: it exists to debug kernels and to time "what a CPU grid

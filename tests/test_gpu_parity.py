@@ -122,7 +122,8 @@ def test_fresh_seeds_vs_oracle(oracle, n, seed):
 
 def test_stencil_order_matches_grid_twin_bitwise(oracle):
     """The default path's summation order is a pure function of (positions, ids): stencil rows
-    dx-major/dy-minor, cells ascending in z, ascending id inside a cell.  The CPU grid twin sums
+    dx-major/dy-minor, cells ascending in z, inside a cell the lower half in z before the upper half and
+    ascending id inside a half.  The CPU grid twin sums
     in that same order, so the two agree to the last bit — which makes the twin a bit-level
     oracle at sizes the all-pairs oracle cannot reach."""
     pos, vel = scenes.jittered_lattice(20, 20, 20, seed=3)
