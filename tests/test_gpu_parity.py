@@ -250,6 +250,37 @@ def test_crowded_cells(oracle, n, spread, flags):
     assert max_rel(gp, pa) <= TOL_ONE_STEP
 
 
+@pytest.mark.parametrize("per_cell_edge", [2, 3, 4])
+def test_particles_on_cell_and_half_cell_boundaries(oracle, per_cell_edge):
+    """Stencil runs leave out the half of an end cell that the particle's own half of its cell puts out of reach, for
+    particles of cells with 8 particles or more.  A lattice whose spacing divides the cell edge puts particles exactly
+    on cell faces and on the planes that halve the cells (2 and 4 per edge: 8 and 64 per cell, both clipped; 3 per
+    edge: 27 per cell, nobody on a half plane), from the floor of the tank (no cell below) to its lid (no cell
+    above, positions clamped into the last cell), a fraction of an ulp around the planes included.  Neighbour counts
+    bit for bit against the all-pairs oracle, the step bit for bit against the grid twin."""
+    p = default_params(flags=REF)
+    p.tank_size = 0.04  # 4 cells per axis: the topmost lattice plane lies in the last cell by clamping
+    cell = np.float32(p.h) * np.float32(1.000244140625)
+    k = 4 * per_cell_edge + 1  # lattice planes from 0 to 4 cell edges inclusive
+    axis = (np.arange(k, dtype=np.float32) * (cell / np.float32(per_cell_edge))).astype(np.float32)
+    xs, ys, zs = np.meshgrid(axis, axis, axis, indexing="ij")
+    pos = np.stack([xs.ravel(), ys.ravel(), zs.ravel()], axis=1).astype(np.float32)
+    # every third particle one ulp below its plane in z, every third one ulp above
+    idx = np.arange(pos.shape[0])
+    pos[idx % 3 == 1, 2] = np.nextafter(pos[idx % 3 == 1, 2], np.float32(-1.0))
+    pos[idx % 3 == 2, 2] = np.nextafter(pos[idx % 3 == 2, 2], np.float32(1.0))
+    pos = np.clip(pos, 0.0, None).astype(np.float32)
+    rng = np.random.default_rng(5)
+    vel = ((rng.random(pos.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.1)).astype(np.float32)
+    po, vo = pos.copy(), vel.copy()
+    (gp, gv), (rho, f, nc, cell_id) = run_gpu(p, pos, vel, 1)
+    assert np.array_equal(nc, oracle.neighbor_counts(p, pos))
+    assert np.array_equal(cell_id, oracle.cell_ids(p, pos))
+    rho_o, f_o, nc_o = oracle.step_grid(p, po, vo, order=0, want_debug=True)
+    assert np.array_equal(nc, nc_o)
+    assert bits_equal(rho, rho_o) and bits_equal(f, f_o) and bits_equal(gp, po) and bits_equal(gv, vo)
+
+
 def test_few_particles_in_a_large_grid(oracle):
     """A 2.1 m tank is 210 cells per side, 9.3M cells (more than 2048 scan tiles: the prefix sum takes its
     three-kernel route), nearly all of them empty; the block sits far from the origin."""
