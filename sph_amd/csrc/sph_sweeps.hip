@@ -31,7 +31,12 @@ namespace sph {
 
 namespace {
 
+// Threads per block of the sweeps: 256 for large launches; 128 below kSmallLaunch particles, where the grid is only a
+// few rounds of blocks deep and finer blocks shorten its tail (1M-particle dam break at peak compression: step 0.477 ->
+// 0.467 ms; at 8M and 16.8M particles the smaller record tile costs the force pass 1 %).
 constexpr int kBlock = 256;
+constexpr int kSmallBlock = 128;
+constexpr int kSmallLaunch = 4 << 20;
 constexpr int kAhead = 4;  // candidates fetched per loop trip of the search
 static_assert(kAhead == 4, "the search unpacks four packed positions out of three 16-byte words");
 struct __attribute__((aligned(4))) Quad {  // 16 bytes at dword alignment
@@ -43,7 +48,7 @@ constexpr int kMaskBits = 32 * kMaskWords;
 // ends 226 / 225 / 254 us for margins of 32 / 64 / 128 slots (5, 5, 4 blocks): what a margin adds in hits it loses in
 // resident blocks.
 constexpr int kTilePad = 0;
-constexpr int kTileRecords = kBlock + 2 * kTilePad;  // 8 KB of LDS
+constexpr int tile_records(int block) { return block + 2 * kTilePad; }  // 8 KB of LDS for 256 threads
 
 __host__ inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 
@@ -138,12 +143,11 @@ __device__ inline bool next_run(const DevParams& P, const int32_t* __restrict__ 
 // of kAhead), and position q of run k is sorted slot shift[k] + q.
 // QE: int where the whole stencil is walked whatever its size (search, density); unsigned short in the force pass, which
 // consults the table only for stencils of at most kMaskBits candidates and wants the LDS for a record tile.
-template <class QE>
+template <class QE, int B>
 struct RunTableT {
-  int (*shift)[kBlock];  // first slot of run k minus the number of candidates before run k
-  QE (*qend)[kBlock];    // number of candidates up to and including run k (saturated at the largest QE)
+  int (*shift)[B];  // first slot of run k minus the number of candidates before run k
+  QE (*qend)[B];    // number of candidates up to and including run k (saturated at the largest QE)
 };
-using RunTable = RunTableT<int>;
 // Returns the number of kAhead-wide trips a walk over all runs takes.
 // Where a stencil run of a particle in cell (.., .., cz) begins and ends in a row of cells, as (table, index) pairs: the
 // cells cz-1 .. cz+1, minus the half of an end cell that the particle's own half of its cell puts out of reach (the
@@ -173,10 +177,10 @@ __device__ inline RunEnds run_ends(const DevParams& P, const int32_t* __restrict
   return r;
 }
 
-template <class QE>
+template <class QE, int B>
 __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start,
                                 const int32_t* __restrict__ mid, const CellCoord cc, int upper,
-                                const RunTableT<QE>& rt) {
+                                const RunTableT<QE, B>& rt) {
   const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
   // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
   // no branch, so that all 18 loads are issued before the first is waited for
@@ -230,18 +234,20 @@ __device__ inline void column_slots(const DevParams& P, const int32_t* __restric
 //  * a candidate past the end of its run gets a squared distance nothing passes, which serves the outcome bit and the
 //    density term alike.
 constexpr int kSearchRuns = 10;  // nine runs and a zero-length entry behind the last
+template <int B>
 struct SearchRuns {
-  unsigned (*boff)[kBlock];  // byte offset of the run's first packed position
-  int (*len)[kBlock];        // candidates in the run
+  unsigned (*boff)[B];  // byte offset of the run's first packed position
+  int (*len)[B];        // candidates in the run
 };
 // Returns the number of kAhead-wide trips the particle's stencil takes.  *tight is set when fewer than kAhead - 1
 // slots lie between the end of one of the particle's runs and the start of its next one (or the end of the sorted
 // array): only then can a slot fetched past the end of a run be a particle that is ALSO a candidate of a later run (or
 // no particle at all).  Everywhere else the slots behind a run belong to cells outside the 27-cell stencil, at least
 // one padded cell away, and fail the distance test by themselves.
+template <int B>
 __device__ inline int fill_search_runs(const DevParams& P, const int32_t* __restrict__ start,
                                        const int32_t* __restrict__ mid, const CellCoord cc, int upper,
-                                       const SearchRuns& rt, int n, bool* tight) {
+                                       const SearchRuns<B>& rt, int n, bool* tight) {
   const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
   int b[9], e[9];
 #pragma unroll
@@ -273,22 +279,22 @@ __device__ inline int fill_search_runs(const DevParams& P, const int32_t* __rest
   return trips;
 }
 
-template <bool WITH_DENSITY>
-__global__ void __launch_bounds__(kBlock) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
+template <int B, bool WITH_DENSITY>
+__global__ void __launch_bounds__(B) k_neighbours(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ mid,
                                                        const int32_t* __restrict__ cell_s, NeighbourMask nm,
                                                        int32_t* __restrict__ ncount, int n) {
-  __shared__ unsigned rt_boff[kSearchRuns][kBlock];
-  __shared__ int rt_len[kSearchRuns][kBlock];
+  __shared__ unsigned rt_boff[kSearchRuns][B];
+  __shared__ int rt_len[kSearchRuns][B];
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
-  const int off = range_first_slot(hi - lo, kBlock, P.dens_hi - P.dens_lo);
+  const int off = range_first_slot(hi - lo, B, P.dens_hi - P.dens_lo);
   const int s = lo + off + threadIdx.x;
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   bool tight;
   const int trips = fill_search_runs(P, start, mid, decode_cell(P, cell_s[s]), upper_half(P, pi.z),
-                                     SearchRuns{rt_boff, rt_len}, n, &tight);
+                                     SearchRuns<B>{rt_boff, rt_len}, n, &tight);
   // One wave, one loop: with the checks of run ends only if some lane of the wave needs them (a wave of the bulk of a
   // fluid does not).
   const bool check_ends = __any(tight);
@@ -475,16 +481,17 @@ __device__ inline void for_each_neighbour(const DevParams& P, const Sorted& st, 
 // rho_i = sum_j m * Wpoly6(|r_i - r_j|), self term included (:131-150).  Written to rec[s].vel.w.
 // FAST (masked flavour only): rho_i = (m c_poly6)_fp32 * sum (h2 - r2)^3 - no square root, no double product, r2 in
 // place of the re-squared rounded r - and 1/rho_i, refined, stored beside it for the force pass.
-template <int MODE, bool FAST>
-__global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
+template <int B, int MODE, bool FAST>
+__global__ void __launch_bounds__(B) k_density(DevParams P, Sorted st, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ mid,
                                                     const int32_t* __restrict__ cell_s,
                                                     int32_t* __restrict__ ncount, NeighbourMask nm) {
-  __shared__ int rt_shift[9][kBlock], rt_qend[9][kBlock];  // used by the masked flavour only
+  __shared__ int rt_shift[9][B], rt_qend[9][B];  // used by the masked flavour only
+  using RunTable = RunTableT<int, B>;
   // slots of the x-columns [dens_lo, dens_hi): own columns plus one ghost column on each side
   int lo, hi;
   column_slots(P, start, P.dens_lo, P.dens_hi, lo, hi);
-  const int off = range_first_slot(hi - lo, kBlock, P.dens_hi - P.dens_lo);
+  const int off = range_first_slot(hi - lo, B, P.dens_hi - P.dens_lo);
   const int first = lo + off;
   const int col = threadIdx.x;
   const int s = first + col;
@@ -546,14 +553,16 @@ __global__ void __launch_bounds__(kBlock) k_density(DevParams P, Sorted st, cons
 }
 
 // ---- forces, integration, walls -------------------------------------------------------------------------------------
-template <int MODE, bool FAST>
-__global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State out, int n,
+template <int B, int MODE, bool FAST>
+__global__ void __launch_bounds__(B) k_force(DevParams P, Sorted st, State out, int n,
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ mid,
                                                   const int32_t* __restrict__ cell_s, float* __restrict__ force_dbg,
                                                   int32_t* __restrict__ n_own_out, NeighbourMask nm) {
-  __shared__ int rt_shift[9][kBlock];  // used by the masked flavour only
-  __shared__ unsigned short rt_qend[9][kBlock];
+  __shared__ int rt_shift[9][B];  // used by the masked flavour only
+  __shared__ unsigned short rt_qend[9][B];
+  using ForceRuns = RunTableT<unsigned short, B>;
+  constexpr int kTileRecords = tile_records(B);
   // This launch advances the slots of the x-columns [force_lo, force_hi), a part (usually all) of the own columns
   // [own_lo, own_hi); the new state is written compactly: own slot s goes to index s - (first own slot).
   int base, bound, own_base, own_bound;
@@ -564,7 +573,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     n_own_out[0] = own_bound - own_base;           // particles this context keeps
     n_own_out[1] = start[real + 1] - start[real];  // trash cell: particles outside the local grid
   }
-  const int first = range_first_slot(bound - base, kBlock, P.force_hi - P.force_lo);
+  const int first = range_first_slot(bound - base, B, P.force_hi - P.force_lo);
   if (first < 0) return;  // whole block beyond the range (uniform: before any barrier)
   const int col = threadIdx.x;
   __shared__ float4 tile_pos[MODE == SWEEP_MASKED ? kTileRecords : 1], tile_vel[MODE == SWEEP_MASKED ? kTileRecords : 1];
@@ -573,11 +582,11 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
     const int s_nat = base + first + threadIdx.x;
     if (s_nat < bound)
       fill_runs(P, start, mid, decode_cell(P, cell_s[s_nat]), upper_half(P, st.pos3[3 * (size_t)s_nat + 2]),
-                RunTableT<unsigned short>{rt_shift, rt_qend});
+                ForceRuns{rt_shift, rt_qend});
     tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
     const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
     tile.n = (unsigned)(tile_hi - tile.lo);
-    for (int t = threadIdx.x; t < (int)tile.n; t += kBlock) {
+    for (int t = threadIdx.x; t < (int)tile.n; t += B) {
       tile_pos[t] = st.rec[tile.lo + t].pos;
       tile_vel[t] = st.rec[tile.lo + t].vel;
     }
@@ -606,7 +615,7 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, RunTableT<unsigned short>{rt_shift, rt_qend}, col, cell_s[s], add_pair,
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, ForceRuns{rt_shift, rt_qend}, col, cell_s[s], add_pair,
                              tile);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
@@ -654,45 +663,67 @@ __global__ void __launch_bounds__(kBlock) k_force(DevParams P, Sorted st, State 
 
 }  // namespace
 
-void launch_neighbours(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
+namespace {
+template <int B>
+void neighbours_on(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
+                   const NeighbourMask& nm, bool with_density, int32_t* ncount) {
+  const dim3 grid(div_up(n, B)), block(B);
+  if (with_density)
+    hipLaunchKernelGGL((k_neighbours<B, true>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
+  else
+    hipLaunchKernelGGL((k_neighbours<B, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
+}
+
+template <int B>
+void density_on(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g, int32_t* ncount,
+                const NeighbourMask& nm, SweepMode mode) {
+  const dim3 grid(div_up(n, B)), block(B);
+  if (mode == SWEEP_EXACT)
+    hipLaunchKernelGGL((k_density<B, SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
+  else if (mode == SWEEP_PLAIN)
+    hipLaunchKernelGGL((k_density<B, SWEEP_PLAIN, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
+  else if (mode == SWEEP_FAST)
+    hipLaunchKernelGGL((k_density<B, SWEEP_MASKED, true>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
+  else
+    hipLaunchKernelGGL((k_density<B, SWEEP_MASKED, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
+}
+
+template <int B>
+void force_on(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n, const GridBuffers& g,
+              float* force_dbg, int32_t* n_own_out, const NeighbourMask& nm, SweepMode mode) {
+  const dim3 grid(div_up(n, B)), block(B);
+  if (mode == SWEEP_EXACT)
+    hipLaunchKernelGGL((k_force<B, SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
+  else if (mode == SWEEP_PLAIN)
+    hipLaunchKernelGGL((k_force<B, SWEEP_PLAIN, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
+  else if (mode == SWEEP_FAST)
+    hipLaunchKernelGGL((k_force<B, SWEEP_MASKED, true>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
+  else
+    hipLaunchKernelGGL((k_force<B, SWEEP_MASKED, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
+}
+}  // namespace
+
+// The launches cover n slots (an upper bound of the range a pass works on); their block size follows n.
+void launch_neighbours(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
                        const NeighbourMask& nm, bool with_density, int32_t* ncount) {
   if (n <= 0) return;
-  const DevParams& P = P0;
-  if (with_density)
-    hipLaunchKernelGGL(k_neighbours<true>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
-  else
-    hipLaunchKernelGGL(k_neighbours<false>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, P, st, g.start, g.mid, g.cell_s, nm, ncount, n);
+  if (n < kSmallLaunch) neighbours_on<kSmallBlock>(s, P, st, n, g, nm, with_density, ncount);
+  else neighbours_on<kBlock>(s, P, st, n, g, nm, with_density, ncount);
 }
 
-void launch_density(hipStream_t s, const DevParams& P0, const Sorted& st, int n, const GridBuffers& g,
+void launch_density(hipStream_t s, const DevParams& P, const Sorted& st, int n, const GridBuffers& g,
                     int32_t* ncount, const NeighbourMask& nm, SweepMode mode) {
   if (n <= 0) return;
-  const DevParams& P = P0;
-  dim3 grid(div_up(n, kBlock)), block(kBlock);
-  if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL((k_density<SWEEP_EXACT, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
-  else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL((k_density<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
-  else if (mode == SWEEP_FAST)
-    hipLaunchKernelGGL((k_density<SWEEP_MASKED, true>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
-  else
-    hipLaunchKernelGGL((k_density<SWEEP_MASKED, false>), grid, block, 0, s, P, st, g.start, g.mid, g.cell_s, ncount, nm);
+  if (n < kSmallLaunch) density_on<kSmallBlock>(s, P, st, n, g, ncount, nm, mode);
+  else density_on<kBlock>(s, P, st, n, g, ncount, nm, mode);
 }
 
-void launch_force(hipStream_t s, const DevParams& P0, const Sorted& st, const State& out, int n,
+void launch_force(hipStream_t s, const DevParams& P, const Sorted& st, const State& out, int n,
                   const GridBuffers& g, float* force_dbg, int32_t* n_own_out, const NeighbourMask& nm,
                   SweepMode mode) {
   if (n <= 0) return;
-  const DevParams& P = P0;
-  dim3 grid(div_up(n, kBlock)), block(kBlock);
-  if (mode == SWEEP_EXACT)
-    hipLaunchKernelGGL((k_force<SWEEP_EXACT, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
-  else if (mode == SWEEP_PLAIN)
-    hipLaunchKernelGGL((k_force<SWEEP_PLAIN, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
-  else if (mode == SWEEP_FAST)
-    hipLaunchKernelGGL((k_force<SWEEP_MASKED, true>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
-  else
-    hipLaunchKernelGGL((k_force<SWEEP_MASKED, false>), grid, block, 0, s, P, st, out, n, g.start, g.mid, g.cell_s, force_dbg, n_own_out, nm);
+  if (n < kSmallLaunch) force_on<kSmallBlock>(s, P, st, out, n, g, force_dbg, n_own_out, nm, mode);
+  else force_on<kBlock>(s, P, st, out, n, g, force_dbg, n_own_out, nm, mode);
 }
 
 }  // namespace sph
