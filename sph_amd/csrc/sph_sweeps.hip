@@ -5,9 +5,10 @@
 // position (search, density) and a 32-byte record with position and velocity + density (force).  Cells are
 // linearised as c = (cx*ny + cy)*nz + cz (z fastest; x, the slab axis, slowest): the 27-cell stencil of a
 // particle is 9 runs of up to 3 z-adjacent cells, each run ONE contiguous slot range.  Runs are visited
-// dx-major, dy-minor; inside a cell the particles of its lower half in z come first, then those of its upper half, each
-// half in ascending id order (so a run can leave out the half of an end cell that is out of the particle's reach).  That order is a pure function of
-// (positions, ids), so results do not depend on how particles share waves, blocks, contexts or slabs.
+// dx-major, dy-minor; inside a cell the particles of its lower half in z come first, then those of its upper half,
+// each half in ascending id order (so a run can leave out the half of an end cell that is out of the particle's
+// reach).  That order is a pure function of (positions, ids), so results do not depend on how particles share waves,
+// blocks, contexts or slabs.
 //
 // Default (SWEEP_MASKED) pipeline, one lane per particle in every kernel:
 //   k_neighbours  the only kernel that tests distances: walks the flattened stencil four candidates per trip
