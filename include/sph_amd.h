@@ -210,7 +210,7 @@ int sph_host_unregister(void* host_ptr);
  * 3*num_particles floats each, advanced in place, issued on `stream` (a hipStream_t; NULL = the null
  * stream) of the CURRENT device and not waited for.  The call allocates and frees nothing: every
  * intermediate buffer is a piece of one static device array inside the library
- * (about 14 MB, held by each GPU the library runs on until the process ends), which bounds the input:
+ * (about 15.5 MB, held by each GPU the library runs on until the process ends), which bounds the input:
  * at most SPH_NOALLOC_MAX_PARTICLES particles and SPH_NOALLOC_MAX_CELLS grid cells
  * (SPH_ERR_CAPACITY beyond); SPH_FLAG_KEEP_DEBUG is rejected.  All calls on one GPU share that
  * array: calls that overlap in time on the same GPU (different streams or threads) race.
