@@ -60,6 +60,22 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
       REP16(asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
                          "v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
                          : "+v"(bits) : : "vcc");)
+    } else if (MODE == 11 || MODE == 12 || MODE == 13) {  // 128 packed fp32 operations on register pairs
+      double d0 = x0, d1 = x1, d2 = x2, d3 = x3, pa = a, pb = b;
+      if (MODE == 11) {
+        REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                           "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                           : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(pa), "v"(pb));)
+      } else if (MODE == 12) {
+        REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                           "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                           : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(pa), "v"(pb));)
+      } else {
+        REP16(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                           "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                           : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(pa), "v"(pb));)
+      }
+      x0 += (float)d0; x1 += (float)d1; x2 += (float)d2; x3 += (float)d3;
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + bits;
@@ -98,5 +114,8 @@ int main() {
   run<8>("v_mov_b64", 128, 8);
   run<9>("v_rsq_f32", 128, 8);
   run<10>("v_addc_co_u32 (vcc chain)", 128, 8);
+  run<11>("v_pk_fma_f32 (two fp32 per lane)", 128, 8);
+  run<12>("v_pk_mul_f32", 128, 8);
+  run<13>("v_pk_add_f32", 128, 8);
   return 0;
 }

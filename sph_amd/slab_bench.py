@@ -25,6 +25,7 @@ import time
 import numpy as np
 
 DEFAULT_SIDE_PER_GPU = 200   # 8M particles per GPU: 8 GPUs hold the 64M-particle dam break
+HANG_DEADLINE_S = 1500       # a rank still running after this long prints every thread's stack and exits
 PEAK_PREROLL_AT_SIDE_100 = 60  # steps until the 100^3 dam break is at peak compression
 
 
@@ -114,7 +115,23 @@ def all_agree(dist, torch, ok):
     return bool(t.item())
 
 
+def arm_deadline():
+    """A transport that never completes (a peer that died, a link that does not come up) would otherwise hang the run
+    without a word: past the deadline (SPH_BENCH_DEADLINE_S, 0 = none) the rank prints every thread's stack to stderr
+    and exits with status 1, and the launcher ends the other ranks."""
+    import faulthandler
+    deadline = float(os.environ.get("SPH_BENCH_DEADLINE_S", HANG_DEADLINE_S))
+    if deadline > 0:
+        faulthandler.dump_traceback_later(deadline, exit=True)
+
+
+def disarm_deadline():
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+
+
 def main(args):
+    arm_deadline()
     import torch
     import torch.distributed as dist
 
@@ -303,3 +320,4 @@ def main(args):
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+    disarm_deadline()

@@ -69,3 +69,15 @@ def test_bench_accepts_only_workloads_the_slab_driver_runs():
     for w in ("dam_break", "sloshing", "uniform_cube"):
         assert w in src
     assert "args.workload" in src
+
+
+def test_a_hung_rank_reports_its_stacks_and_exits():
+    code = "from sph_amd import slab_bench; import time; slab_bench.arm_deadline(); time.sleep(20)"
+    env = dict(os.environ, SPH_BENCH_DEADLINE_S="0.5", PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=15)
+    assert res.returncode == 1
+    assert "Timeout" in res.stderr and "time.sleep" not in res.stdout
+    # disarmed: the process runs to its end
+    code = "from sph_amd import slab_bench; import time; slab_bench.arm_deadline(); slab_bench.disarm_deadline(); time.sleep(1)"
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=15)
+    assert res.returncode == 0
