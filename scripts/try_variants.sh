@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development aid: build libsph_amd.so variants with -D overrides (sweep kernels only, the Makefile's flags) and time
+# Development aid: build libsph_amd.so variants with -D overrides (both kernel files, the Makefile's flags) and time
 # each on the GPU box.
 # usage (CPU side): scripts/try_variants.sh build "NAME:-DFOO=1" ...
 #       (GPU side): scripts/try_variants.sh run <scene> <side> <first_step> <steps> NAME...
@@ -11,7 +11,8 @@ if [ "$mode" = build ]; then
     name=${v%%:*}; defs=${v#*:}
     ( cd sph_amd/csrc &&
       hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 $defs -c sph_sweeps.hip -o /tmp/var_sweeps_$name.o &&
-      hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libsph_amd_$name.so sph_kernels.o /tmp/var_sweeps_$name.o sph_render.o sph_api.o sph_rccl.o -ldl ) || exit 1
+      hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 $defs -c sph_kernels.hip -o /tmp/var_kernels_$name.o &&
+      hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libsph_amd_$name.so /tmp/var_kernels_$name.o /tmp/var_sweeps_$name.o sph_render.o sph_api.o sph_rccl.o -ldl ) || exit 1
     echo built $name
   done
 else

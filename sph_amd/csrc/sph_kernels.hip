@@ -288,38 +288,81 @@ __global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int3
 // in-cell order no longer depends on the order in which the histogram atomics happened to be served.  The lanes of a
 // wave are consecutive slots, hence mostly cell-mates that count over the same keys: those loads are one request per
 // wave.  The cell's first particle in the new order also records where the cell's upper half begins.
-__global__ void k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ start, int32_t* __restrict__ mid,
-                          const int32_t* __restrict__ src_of, const int32_t* __restrict__ id_prov,
-                          const int32_t* __restrict__ cell_s) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const int i = src_of[s];
-  const unsigned my = (unsigned)id_prov[s];
-  const int c = cell_s[s];
-  const int b = start[c], e = start[c + 1];
-  const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);
-  const float4 vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);
-  int r = 0, uppers = 0;
-  int t = b;
-  for (; t + 4 <= e; t += 4) {  // four independent loads per trip
-    const unsigned a0 = (unsigned)id_prov[t], a1 = (unsigned)id_prov[t + 1], a2 = (unsigned)id_prov[t + 2],
-                   a3 = (unsigned)id_prov[t + 3];
-    r += (a0 < my) + (a1 < my) + (a2 < my) + (a3 < my);
-    uppers += (int)((a0 >> 31) + (a1 >> 31) + (a2 >> 31) + (a3 >> 31));
+//
+// The final slot lies in the particle's own cell, so all but the particles of the two cells that straddle the block's
+// ends stay inside the block's own 256 slots: they are put in order in LDS and leave as whole lines (per lane a
+// 12-byte, a 32-byte and a 4-byte piece at its own stride would be five partial-line stores per particle).  A slot
+// of the block's range that is filled by a neighbouring block stays marked empty here and is not written.
+#ifndef SPH_REORDER_STAGED
+#define SPH_REORDER_STAGED 1
+#endif
+__global__ void __launch_bounds__(kBlock) k_reorder(int n, State in, Sorted out, const int32_t* __restrict__ start,
+                                                    int32_t* __restrict__ mid, const int32_t* __restrict__ src_of,
+                                                    const int32_t* __restrict__ id_prov,
+                                                    const int32_t* __restrict__ cell_s) {
+  __shared__ float s_pos3[3 * kBlock];
+  __shared__ float4 s_rec[2 * kBlock];
+  __shared__ int s_id[kBlock];  // -1: no particle of this block goes there
+  const int base = blockIdx.x * kBlock;
+  const int s = base + threadIdx.x;
+  s_id[threadIdx.x] = -1;
+  __syncthreads();
+  if (s < n) {
+    const int i = src_of[s];
+    const unsigned my = (unsigned)id_prov[s];
+    const int c = cell_s[s];
+    const int b = start[c], e = start[c + 1];
+    const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);  // w receives 1/density
+    const float4 vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
+    int r = 0, uppers = 0;
+    int t = b;
+    for (; t + 4 <= e; t += 4) {  // four independent loads per trip
+      const unsigned a0 = (unsigned)id_prov[t], a1 = (unsigned)id_prov[t + 1], a2 = (unsigned)id_prov[t + 2],
+                     a3 = (unsigned)id_prov[t + 3];
+      r += (a0 < my) + (a1 < my) + (a2 < my) + (a3 < my);
+      uppers += (int)((a0 >> 31) + (a1 >> 31) + (a2 >> 31) + (a3 >> 31));
+    }
+    for (; t < e; t++) {
+      const unsigned a = (unsigned)id_prov[t];
+      r += a < my;
+      uppers += (int)(a >> 31);
+    }
+    const int d = b + r;
+    if (r == 0) mid[c] = e - uppers;
+    const int id = (int)(my & 0x7fffffffu);
+    const unsigned l = (unsigned)(d - base);
+    if (SPH_REORDER_STAGED && l < (unsigned)kBlock) {
+      s_pos3[3 * l + 0] = pos.x;
+      s_pos3[3 * l + 1] = pos.y;
+      s_pos3[3 * l + 2] = pos.z;
+      s_rec[2 * l + 0] = pos;
+      s_rec[2 * l + 1] = vel;
+      s_id[l] = id;
+    } else {
+      out.pos3[3 * (size_t)d + 0] = pos.x;
+      out.pos3[3 * (size_t)d + 1] = pos.y;
+      out.pos3[3 * (size_t)d + 2] = pos.z;
+      out.rec[d].pos = pos;
+      out.rec[d].vel = vel;
+      out.id[d] = id;
+    }
   }
-  for (; t < e; t++) {
-    const unsigned a = (unsigned)id_prov[t];
-    r += a < my;
-    uppers += (int)(a >> 31);
+  if (!SPH_REORDER_STAGED) return;
+  __syncthreads();
+  const int mine = s_id[threadIdx.x];
+  if (mine >= 0) out.id[s] = mine;
+  float* pos3_out = out.pos3 + 3 * (size_t)base;
+  float4* rec_out = reinterpret_cast<float4*>(out.rec + base);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int w = k * kBlock + threadIdx.x;
+    if (s_id[(w * 21846) >> 16] >= 0) pos3_out[w] = s_pos3[w];  // w / 3 for w < 768
   }
-  const int d = b + r;
-  if (r == 0) mid[c] = e - uppers;
-  out.pos3[3 * (size_t)d + 0] = pos.x;
-  out.pos3[3 * (size_t)d + 1] = pos.y;
-  out.pos3[3 * (size_t)d + 2] = pos.z;
-  out.rec[d].pos = pos;  // w receives 1/density
-  out.rec[d].vel = vel;  // w receives the density
-  out.id[d] = (int)(my & 0x7fffffffu);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int w = k * kBlock + threadIdx.x;
+    if (s_id[w >> 1] >= 0) rec_out[w] = s_rec[w];
+  }
 }
 
 // ---- slab decomposition: halo/migration records ---------------------------------------------------------------
