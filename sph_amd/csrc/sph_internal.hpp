@@ -65,6 +65,16 @@ struct ParticleRec {
 // The neighbour search reads up to kSearchOverread slots past the end of a stencil run (and masks them off), so
 // `pos` is allocated that much longer than the particle capacity.
 constexpr int kSearchOverread = 4;
+// Stencil runs are clipped by half cells (see run_ends() in sph_sweeps.hip) only for particles of cells that hold
+// kClipFrom particles or more.  The counting sort knows a cell's size when it places a particle, and leaves the
+// verdict in bit 31 of the particle's entry of the sorted cell array: the sweeps then need no look at the start table
+// before they can ask for their eighteen run ends.
+#ifndef SPH_CLIP_FROM
+#define SPH_CLIP_FROM 8
+#endif
+constexpr int kClipFrom = SPH_CLIP_FROM;
+constexpr int32_t kCellClipBit = (int32_t)0x80000000u;
+constexpr int32_t kCellMask = 0x7fffffff;
 struct Sorted {
   float* pos3;  // x y z packed, 12 bytes per particle: four candidates of the search are three 16-byte loads
   ParticleRec* rec;
@@ -94,7 +104,7 @@ struct GridBuffers {
   int32_t* rank_of;    // [n] arrival rank of particle i in its cell (arbitrary, from the atomic)
   int32_t* src_of;     // [n] provisional slot -> pre-sort index
   int32_t* id_prov;    // [n] provisional slot -> particle id
-  int32_t* cell_s;     // [n] sorted slot -> cell
+  int32_t* cell_s;     // [n] sorted slot -> cell; bit 31 (kCellClipBit): the cell holds kClipFrom particles or more
   size_t ncells;
   size_t scan_blocks;
 };

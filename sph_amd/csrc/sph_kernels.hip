@@ -59,7 +59,7 @@ __global__ void k_gather_debug(const int32_t* __restrict__ id, int n, const Part
     force[3 * i + 2] = force_s[2 * (size_t)n + s];
   }
   if (ncount) ncount[i] = ncount_s[s];
-  if (cell) cell[i] = cell_s[s];
+  if (cell) cell[i] = cell_s[s] & kCellMask;
 }
 
 // ---- hash + histogram ---------------------------------------------------------------------------------
@@ -278,10 +278,11 @@ __global__ void k_scatter(int n, const int32_t* __restrict__ cell_of, const int3
   if (i >= n) return;
   const int c = cell_of[i];
   const int rw = rank_of[i];  // bit 31: upper half of the cell
-  const int slot = start[c] + (rw & 0x7fffffff);
+  const int b = start[c], e = start[c + 1];
+  const int slot = b + (rw & 0x7fffffff);
   src_of[slot] = i;
   id_prov[slot] = id_in[i] | (rw & (int)0x80000000u);  // ids are below 2^31: the sort key is (half, id)
-  cell_s[slot] = c;
+  cell_s[slot] = c | (e - b >= kClipFrom ? kCellClipBit : 0);  // cells are counted in 31 bits; bit 31: runs clip
 }
 
 // Final slot = cell start + number of cell-mates with a smaller key, the key being (half of the cell in z, id): the
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) k_reorder(int n, State in, Sorted out,
   if (s < n) {
     const int i = src_of[s];
     const unsigned my = (unsigned)id_prov[s];
-    const int c = cell_s[s];
+    const int c = cell_s[s] & kCellMask;
     const int b = start[c], e = start[c + 1];
     const float4 pos = make_float4(in.x[i], in.y[i], in.z[i], 0.0f);  // w receives 1/density
     const float4 vel = make_float4(in.vx[i], in.vy[i], in.vz[i], 0.0f);  // w receives the density
@@ -575,7 +576,7 @@ __global__ void k_join_debug(DevParams P, const int32_t* __restrict__ start, int
     force[3 * o + 2] = force_o[2 * (size_t)n_stride + o];
   }
   if (ncount) ncount[o] = ncount_s[s];
-  if (cell) cell[o] = cell_s[s];
+  if (cell) cell[o] = cell_s[s] & kCellMask;
 }
 
 // ---- scene generation on the device -----------------------------------------------------------------------------------

@@ -159,17 +159,13 @@ struct RunEnds {
   const int32_t* last_table;
   int first, last;  // cell offsets within a row: the run is [first_table[row + first], last_table[row + last])
 };
-// Only particles of well-filled cells clip their runs (kClipFrom particles or more in the particle's own cell, which
-// every pass can read off the start table): the lanes of a cell then fall into two groups with different runs, and
-// where cells hold three particles that costs the vector cache more merged lookups than the shorter runs save.
-#ifndef SPH_CLIP_FROM
-#define SPH_CLIP_FROM 8
-#endif
-constexpr int kClipFrom = SPH_CLIP_FROM;
+// Only particles of well-filled cells clip their runs (kClipFrom particles or more in the particle's own cell; the
+// counting sort leaves that verdict in bit 31 of the particle's sorted cell word): the lanes of a cell then fall into
+// two groups with different runs, and where cells hold three particles that costs the vector cache more merged lookups
+// than the shorter runs save.
 __device__ inline RunEnds run_ends(const DevParams& P, const int32_t* __restrict__ start,
-                                   const int32_t* __restrict__ mid, int cell, int cz, int upper) {
+                                   const int32_t* __restrict__ mid, bool clip, int cz, int upper) {
   RunEnds r;
-  const bool clip = start[cell + 1] - start[cell] >= kClipFrom;
   r.first_table = (clip && upper && cz > 0) ? mid : start;
   r.first = cz > 0 ? cz - 1 : 0;
   const bool clip_top = clip && !upper && cz < P.nz - 1;
@@ -180,9 +176,9 @@ __device__ inline RunEnds run_ends(const DevParams& P, const int32_t* __restrict
 
 template <class QE, int B>
 __device__ inline int fill_runs(const DevParams& P, const int32_t* __restrict__ start,
-                                const int32_t* __restrict__ mid, const CellCoord cc, int upper,
+                                const int32_t* __restrict__ mid, const CellCoord cc, bool clip, int upper,
                                 const RunTableT<QE, B>& rt) {
-  const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
+  const RunEnds re = run_ends(P, start, mid, clip, cc.z, upper);
   // rows beyond the grid are read as the nearest row inside it (any valid address) and recorded as empty runs;
   // no branch, so that all 18 loads are issued before the first is waited for
   int b[9], e[9];
@@ -247,9 +243,9 @@ struct SearchRuns {
 // one padded cell away, and fail the distance test by themselves.
 template <int B>
 __device__ inline int fill_search_runs(const DevParams& P, const int32_t* __restrict__ start,
-                                       const int32_t* __restrict__ mid, const CellCoord cc, int upper,
+                                       const int32_t* __restrict__ mid, const CellCoord cc, bool clip, int upper,
                                        const SearchRuns<B>& rt, int n, bool* tight) {
-  const RunEnds re = run_ends(P, start, mid, (cc.x * P.ny + cc.y) * P.nz + cc.z, cc.z, upper);
+  const RunEnds re = run_ends(P, start, mid, clip, cc.z, upper);
   int b[9], e[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {  // branch-free: all 18 loads are issued before the first is waited for
@@ -294,7 +290,8 @@ __global__ void __launch_bounds__(B) k_neighbours(DevParams P, Sorted st, const 
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
   bool tight;
-  const int trips = fill_search_runs(P, start, mid, decode_cell(P, cell_s[s]), upper_half(P, pi.z),
+  const int cw = cell_s[s];  // bit 31: the particle's cell is full enough for clipped runs
+  const int trips = fill_search_runs(P, start, mid, decode_cell(P, cw & kCellMask), cw < 0, upper_half(P, pi.z),
                                      SearchRuns<B>{rt_boff, rt_len}, n, &tight);
   // One wave, one loop: with the checks of run ends only if some lane of the wave needs them (a wave of the bulk of a
   // fluid does not).
@@ -498,9 +495,10 @@ __global__ void __launch_bounds__(B) k_density(DevParams P, Sorted st, const int
   const int s = first + col;
   if (off < 0 || s >= hi) return;
   const float4 pi = sorted_pos(st, s);
-  const CellCoord cc = decode_cell(P, cell_s[s]);
+  const int cw = cell_s[s];  // bit 31: the particle's cell is full enough for clipped runs
+  const CellCoord cc = decode_cell(P, cw & kCellMask);
   if (MODE == SWEEP_MASKED)  // own column: no barrier needed
-    fill_runs(P, start, mid, cc, upper_half(P, pi.z), RunTable{rt_shift, rt_qend});
+    fill_runs(P, start, mid, cc, cw < 0, upper_half(P, pi.z), RunTable{rt_shift, rt_qend});
   float acc = 0.0f;
   int cnt = 0;
   float dx, dy, dz;
@@ -514,7 +512,7 @@ __global__ void __launch_bounds__(B) k_density(DevParams P, Sorted st, const int
     cnt++;
   };
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<false>(P, st, start, nm, s, pi, RunTable{rt_shift, rt_qend}, col, cell_s[s],
+    for_each_neighbour<false>(P, st, start, nm, s, pi, RunTable{rt_shift, rt_qend}, col, cw & kCellMask,
                               [&](const float4& pj, const float4&) { add(dist2_to(pi, pj, dx, dy, dz)); });
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
@@ -581,9 +579,11 @@ __global__ void __launch_bounds__(B) k_force(DevParams P, Sorted st, State out, 
   RecordTile tile{tile_pos, tile_vel, 0, 0u};
   if (MODE == SWEEP_MASKED) {
     const int s_nat = base + first + threadIdx.x;
-    if (s_nat < bound)
-      fill_runs(P, start, mid, decode_cell(P, cell_s[s_nat]), upper_half(P, st.pos3[3 * (size_t)s_nat + 2]),
+    if (s_nat < bound) {
+      const int cw = cell_s[s_nat];  // bit 31: the particle's cell is full enough for clipped runs
+      fill_runs(P, start, mid, decode_cell(P, cw & kCellMask), cw < 0, upper_half(P, st.pos3[3 * (size_t)s_nat + 2]),
                 ForceRuns{rt_shift, rt_qend});
+    }
     tile.lo = base + first - kTilePad > 0 ? base + first - kTilePad : 0;
     const int tile_hi = tile.lo + kTileRecords < n ? tile.lo + kTileRecords : n;
     tile.n = (unsigned)(tile_hi - tile.lo);
@@ -600,7 +600,8 @@ __global__ void __launch_bounds__(B) k_force(DevParams P, Sorted st, State out, 
   const float4 vi4 = st.rec[s].vel;  // w = density
   const float rho_i = vi4.w;
   const float pi = P.c2 * (rho_i - P.rho0);  // :158
-  const CellCoord cc = decode_cell(P, cell_s[s]);
+  const int cell_i = cell_s[s] & kCellMask;
+  const CellCoord cc = decode_cell(P, cell_i);
   float a[kForceComps] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float dx, dy, dz;
 
@@ -616,7 +617,7 @@ __global__ void __launch_bounds__(B) k_force(DevParams P, Sorted st, State out, 
   };
 
   if (MODE == SWEEP_MASKED) {
-    for_each_neighbour<true>(P, st, start, nm, s, pi4, ForceRuns{rt_shift, rt_qend}, col, cell_s[s], add_pair,
+    for_each_neighbour<true>(P, st, start, nm, s, pi4, ForceRuns{rt_shift, rt_qend}, col, cell_i, add_pair,
                              tile);
   } else if (MODE == SWEEP_PLAIN) {
     RunCursor c{-1, 0, 0};
