@@ -132,6 +132,9 @@ def disarm_deadline():
 
 def main(args):
     arm_deadline()
+    # RCCL shares device memory between the ranks' processes through dmabuf handles; the legacy IPC mode is not
+    # supported by the host driver of these machines.  Must be in the environment before the HIP runtime starts.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
